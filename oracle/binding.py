@@ -1,0 +1,273 @@
+"""ctypes binding of the CPU oracle (oracle/librt_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The neutral scene description it consumes (a list of object tuples, see
+``ray-tracer_amd/scenes.py``) is the same one the product binding consumes, so a test builds
+one description and hands it to both sides.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librt_oracle.so")
+
+MATH_LIBM = 0
+MATH_DET = 1
+
+TEX_COLOUR, TEX_GRADIENT, TEX_CHECKERBOARD, TEX_IMAGE = 0, 1, 2, 3
+MAT_STANDARD, MAT_EMISSIVE, MAT_REFRACTIVE = 0, 1, 2
+
+
+class Material(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32), ("tex_type", C.c_int32),
+        ("colour", C.c_float * 3), ("light", C.c_float * 3), ("dark", C.c_float * 3),
+        ("num_squares", C.c_int32), ("img_w", C.c_int32), ("img_h", C.c_int32),
+        ("img_rgb", C.POINTER(C.c_float)),
+        ("smoothness", C.c_float), ("need_uv", C.c_int32),
+        ("emitted", C.c_float * 3), ("refractive_index", C.c_float),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("samples", "bounce_iters", "hits", "rng_draws", "sphere_tests", "sphere_hits", "tri_tests", "box_tests")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def build(force=False):
+    """Compile oracle/librt_oracle.so with the committed Makefile (gcc only)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        build()
+    L = C.CDLL(_LIB_PATH)
+    f3 = C.POINTER(C.c_float)
+    L.orc_scene_new.restype = C.c_void_p
+    L.orc_scene_new.argtypes = [C.c_int]
+    L.orc_scene_free.argtypes = [C.c_void_p]
+    L.orc_scene_num_objects.argtypes = [C.c_void_p]
+    L.orc_material_standard.argtypes = [C.POINTER(Material), C.c_int, f3, C.c_float]
+    L.orc_material_checkerboard.argtypes = [C.POINTER(Material), f3, f3, C.c_int, C.c_float]
+    L.orc_material_emissive.argtypes = [C.POINTER(Material), f3, C.c_float]
+    L.orc_material_refractive.argtypes = [C.POINTER(Material), f3, C.c_float]
+    L.orc_add_sphere.argtypes = [C.c_void_p, f3, C.c_float, C.POINTER(Material)]
+    L.orc_add_triangle.argtypes = [C.c_void_p, f3, f3, f3, C.POINTER(Material)]
+    L.orc_add_triangle_uv.argtypes = [C.c_void_p, f3, f3, C.POINTER(Material)]
+    L.orc_add_quad.argtypes = [C.c_void_p, f3, f3, f3, f3, C.POINTER(Material)]
+    L.orc_add_one_way_quad.argtypes = [C.c_void_p, f3, f3, f3, f3, C.c_int, C.POINTER(Material)]
+    L.orc_add_cuboid.argtypes = [C.c_void_p, f3, C.c_float, C.c_float, C.c_float, C.POINTER(Material)]
+    L.orc_add_mesh.argtypes = [C.c_void_p, f3, C.c_int, C.POINTER(Material)]
+    L.orc_add_mesh_faces.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Material)]
+    L.orc_mesh_bvh_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    L.orc_trace_one.argtypes = [C.c_void_p, f3, f3, f3]
+    L.orc_obj_load.restype = C.c_void_p
+    L.orc_obj_load.argtypes = [C.c_char_p, C.c_int]
+    L.orc_obj_free.argtypes = [C.c_void_p]
+    L.orc_obj_enlarge.argtypes = [C.c_void_p, C.c_float]
+    L.orc_obj_rotate.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    L.orc_obj_translate.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float]
+    for n in ("orc_obj_num_vertices", "orc_obj_num_faces", "orc_obj_num_triangles"):
+        getattr(L, n).argtypes = [C.c_void_p]
+    L.orc_obj_face_arity.argtypes = [C.c_void_p, C.c_int]
+    L.orc_obj_vertices.argtypes = [C.c_void_p, f3]
+    L.orc_obj_triangles.argtypes = [C.c_void_p, f3]
+    L.orc_camera_default.argtypes = [C.c_int, C.c_int, C.c_int, f3]
+    L.orc_render.argtypes = [C.c_void_p, f3, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, f3,
+                             C.c_int32, C.c_int32, C.c_int, C.c_int, f3, f3, C.c_int, C.POINTER(Stats)]
+    L.orc_pcg_next.restype = C.c_float
+    L.orc_pcg_next.argtypes = [C.POINTER(C.c_uint32)]
+    L.orc_normal_next.restype = C.c_float
+    L.orc_normal_next.argtypes = [C.POINTER(C.c_uint32), C.c_int]
+    for n in ("orc_math_logf", "orc_math_cosf", "orc_math_sinf", "orc_math_tanf"):
+        getattr(L, n).restype = C.c_float
+        getattr(L, n).argtypes = [C.c_float, C.c_int]
+    L.orc_to_rgba8.argtypes = [f3, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
+    _lib = L
+    return L
+
+
+def _f3(a):
+    arr = np.ascontiguousarray(a, dtype=np.float32)
+    return arr, arr.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def make_material(desc):
+    """desc: ('standard', colour, smoothness) | ('emissive', colour, strength) |
+    ('checkerboard', light, dark, num_squares, smoothness) | ('gradient', smoothness) |
+    ('refractive', colour, n)"""
+    L = lib()
+    m = Material()
+    kind = desc[0]
+    if kind == "standard":
+        _, p = _f3(desc[1])
+        L.orc_material_standard(C.byref(m), TEX_COLOUR, p, C.c_float(desc[2]))
+    elif kind == "gradient":
+        L.orc_material_standard(C.byref(m), TEX_GRADIENT, None, C.c_float(desc[1]))
+    elif kind == "checkerboard":
+        _, pl = _f3(desc[1])
+        _, pd = _f3(desc[2])
+        L.orc_material_checkerboard(C.byref(m), pl, pd, int(desc[3]), C.c_float(desc[4]))
+    elif kind == "emissive":
+        _, p = _f3(desc[1])
+        L.orc_material_emissive(C.byref(m), p, C.c_float(desc[2]))
+    elif kind == "refractive":
+        _, p = _f3(desc[1])
+        L.orc_material_refractive(C.byref(m), p, C.c_float(desc[2]))
+    else:
+        raise ValueError(kind)
+    return m
+
+
+class Obj:
+    """ObjFileMesh (reference src/obj_read.cu:47-147)."""
+
+    def __init__(self, path, math_mode):
+        self._h = lib().orc_obj_load(os.fsencode(path), math_mode)
+        if not self._h:
+            raise RuntimeError("Could not find file to open.")
+
+    def enlarge(self, s):
+        lib().orc_obj_enlarge(self._h, C.c_float(s))
+
+    def rotate(self, x, y, z):
+        lib().orc_obj_rotate(self._h, C.c_float(x), C.c_float(y), C.c_float(z))
+
+    def translate(self, x, y, z):
+        lib().orc_obj_translate(self._h, C.c_float(x), C.c_float(y), C.c_float(z))
+
+    @property
+    def num_vertices(self):
+        return lib().orc_obj_num_vertices(self._h)
+
+    @property
+    def num_faces(self):
+        return lib().orc_obj_num_faces(self._h)
+
+    def face_arities(self):
+        return [lib().orc_obj_face_arity(self._h, i) for i in range(self.num_faces)]
+
+    def vertices(self):
+        out = np.empty((self.num_vertices, 3), np.float32)
+        lib().orc_obj_vertices(self._h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def triangles(self):
+        n = lib().orc_obj_num_triangles(self._h)
+        if n < 0:
+            raise ValueError("Only triangle or quad meshes are supported.")
+        out = np.empty((n, 9), np.float32)
+        lib().orc_obj_triangles(self._h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_obj_free(self._h)
+            self._h = None
+
+
+class Scene:
+    def __init__(self, objects, math_mode=MATH_DET, models_dir=None):
+        """objects: neutral description, see ray-tracer_amd/scenes.py"""
+        L = lib()
+        self.math_mode = math_mode
+        self._h = L.orc_scene_new(math_mode)
+        self._keep = []
+        for o in objects:
+            kind = o[0]
+            m = make_material(o[-1])
+            if kind == "sphere":
+                _, c = _f3(o[1])
+                L.orc_add_sphere(self._h, c, C.c_float(o[2]), C.byref(m))
+            elif kind == "triangle":
+                ps = [_f3(p) for p in o[1:4]]
+                L.orc_add_triangle(self._h, ps[0][1], ps[1][1], ps[2][1], C.byref(m))
+            elif kind == "triangle_uv":
+                a, p = _f3(np.asarray(o[1]).reshape(9))
+                b, q = _f3(np.asarray(o[2]).reshape(6))
+                L.orc_add_triangle_uv(self._h, p, q, C.byref(m))
+            elif kind == "quad":
+                ps = [_f3(p) for p in o[1:5]]
+                L.orc_add_quad(self._h, ps[0][1], ps[1][1], ps[2][1], ps[3][1], C.byref(m))
+            elif kind == "one_way_quad":
+                ps = [_f3(p) for p in o[1:5]]
+                L.orc_add_one_way_quad(self._h, ps[0][1], ps[1][1], ps[2][1], ps[3][1], int(bool(o[5])), C.byref(m))
+            elif kind == "cuboid":
+                _, p = _f3(o[1])
+                L.orc_add_cuboid(self._h, p, C.c_float(o[2]), C.c_float(o[3]), C.c_float(o[4]), C.byref(m))
+            elif kind == "mesh":            # ('mesh', tris[n,9], material)
+                a, p = _f3(np.asarray(o[1]).reshape(-1, 9))
+                L.orc_add_mesh(self._h, p, a.shape[0], C.byref(m))
+            elif kind == "obj":             # ('obj', filename, [('enlarge', s), ('rotate', x,y,z), ('translate', x,y,z)], material)
+                path = o[1] if os.path.isabs(o[1]) or models_dir is None else os.path.join(models_dir, o[1])
+                ob = Obj(path, math_mode)
+                for t in o[2]:
+                    getattr(ob, t[0])(*t[1:])
+                if L.orc_add_mesh_faces(self._h, ob._h, C.byref(m)) != 0:
+                    raise ValueError("Only triangle or quad meshes are supported.")
+            else:
+                raise ValueError(kind)
+
+    def bvh_info(self, object_index, hist_len=8):
+        n = C.c_int()
+        hist = (C.c_int * hist_len)()
+        if lib().orc_mesh_bvh_info(self._h, object_index, C.byref(n), hist, hist_len) != 0:
+            raise ValueError("not a mesh")
+        return n.value, list(hist)
+
+    def trace_one(self, origin, direction):
+        _, o = _f3(origin)
+        _, d = _f3(direction)
+        out = np.zeros(8, np.float32)
+        hit = lib().orc_trace_one(self._h, o, d, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return bool(hit), out
+
+    def render(self, cam, W, H, spp, limit, sky, time_ms=12345, frame_num=0, antialias=True,
+               prev=None, y0=0, y1=None, nthreads=None, out=None, with_stats=False):
+        camarr, camp = _f3(cam)
+        skyarr, skyp = _f3(sky)
+        if out is None:
+            out = np.zeros((H, W, 3), np.float32)
+        prevp = None
+        if prev is not None:
+            prev = np.ascontiguousarray(prev, np.float32)
+            prevp = prev.ctypes.data_as(C.POINTER(C.c_float))
+        st = Stats()
+        lib().orc_render(self._h, camp, W, H, spp, limit, int(bool(antialias)), skyp, time_ms, frame_num,
+                         y0, H if y1 is None else y1, prevp, out.ctypes.data_as(C.POINTER(C.c_float)),
+                         nthreads or (os.cpu_count() or 1), C.byref(st))
+        return (out, st.as_dict()) if with_stats else out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_scene_free(self._h)
+            self._h = None
+
+
+def camera_default(W, H, math_mode=MATH_DET):
+    out = np.zeros(12, np.float32)
+    lib().orc_camera_default(W, H, math_mode, out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def pcg_stream(seed, n):
+    st = C.c_uint32(seed & 0xFFFFFFFF)
+    vals = []
+    for _ in range(n):
+        vals.append(float(lib().orc_pcg_next(C.byref(st))))
+    return vals, st.value

@@ -1,0 +1,147 @@
+/*
+ * rt_math.h — deterministic single-precision transcendentals for the path tracer.
+ *
+ * Why this exists: the reference calls log/cos (device: src/utils.cu:236-238) and
+ * tan/sin/cos (host: src/camera.cu:47, src/matrix.cu:139-140) from the platform libm.
+ * A path tracer turns a 1-ulp difference in one of those into a different hit/miss
+ * decision, so "CPU result == GPU result" needs transcendentals that are the SAME
+ * function on both sides.  Everything below is built only from IEEE-754 binary32
+ * + - * / (plus integer bit operations, and binary64 + - * for the huge-argument
+ * path of sin/cos), never from fma, so it evaluates bit-identically under
+ *   gcc   -O2 -ffp-contract=off           (oracle "det" mode, host code)
+ *   hipcc -O3 -ffp-contract=off gfx950    (device code; f32 denormals are on, / and sqrt
+ *                                          are correctly rounded by default in HIP).
+ *
+ * Accuracy (measured in tests/test_math.py against glibc): rt_logf <= 1 ulp on the
+ * RNG's range, rt_sinf/rt_cosf <= 1 ulp absolute-in-[0,1] terms for |x| <= 3000.
+ * They are NOT bit-identical to glibc or to CUDA's libdevice; DESIGN.md explains what
+ * that means for parity.
+ *
+ * The header is plain C99 / C++ / HIP.
+ */
+#ifndef RT_MATH_H
+#define RT_MATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ static inline
+#else
+#define RT_HD static inline
+#endif
+
+RT_HD uint32_t rt_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+RT_HD float rt_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+
+/* ---- natural logarithm ------------------------------------------------------------
+ * x = 2^k * m, m in [sqrt(1/2), sqrt(2)); f = m - 1; s = f / (2 + f); z = s^2.
+ * log(1+f) = 2 atanh(s) = f - f^2/2 + s (f^2/2 + R),  R = z (2/3 + 2/5 z + 2/7 z^2 + 2/9 z^3)
+ * (series truncation 2/11 z^5 < 2e-9 relative for |s| <= 0.1716).
+ * log(0) = -inf and log(1) = 0 exactly: the reference's Box-Muller feeds both
+ * (SURVEY.md App. A.13). */
+RT_HD float rt_logf(float x)
+{
+    const float LN2_HI = 0.693145751953125f;      /* 0x3f317200, 15 significant bits: k*LN2_HI exact */
+    const float LN2_LO = 1.428606765330187e-06f;  /* 0x35bfbe8e */
+    uint32_t ix = rt_f2u(x);
+    int k = 0;
+    if (ix < 0x00800000u || (ix >> 31)) {
+        if ((ix << 1) == 0u) return rt_u2f(0xff800000u);   /* +-0 -> -inf */
+        if (ix >> 31) return rt_u2f(0x7fc00000u);          /* negative -> NaN */
+        x = x * 33554432.0f;                               /* subnormal: scale by 2^25 */
+        k = -25;
+        ix = rt_f2u(x);
+    } else if (ix >= 0x7f800000u) {
+        return x + x;                                      /* inf, NaN */
+    }
+    k += (int)(ix >> 23) - 127;
+    uint32_t m = ix & 0x007fffffu;
+    uint32_t mb;
+    if (m >= 0x003504f4u) { mb = m | 0x3f000000u; k += 1; }   /* m >= sqrt(2): use m/2 */
+    else                  { mb = m | 0x3f800000u; }
+    float f = rt_u2f(mb) - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float R = z * (0.6666666666666666f + z * (0.4f + z * (0.2857142857142857f + z * 0.2222222222222222f)));
+    float hfsq = 0.5f * f * f;
+    float dk = (float)k;
+    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
+/* ---- sine / cosine -----------------------------------------------------------------
+ * Argument reduction r = x - n*pi/2 with pi/2 split into three 13-bit chunks + a tail,
+ * so n*chunk is exact for |n| <= 2048; beyond that (host-only use) the reduction runs in
+ * binary64.  Kernels on [-pi/4, pi/4] are the Taylor polynomials through r^9 / r^10. */
+RT_HD float rt__sin_k(float r)
+{
+    float z = r * r;
+    float p = -1.6666666666666666e-01f + z * (8.3333333333333332e-03f + z * (-1.9841269841269841e-04f + z * 2.7557319223985893e-06f));
+    return r + r * (z * p);
+}
+
+RT_HD float rt__cos_k(float r)
+{
+    float z = r * r;
+    float p = 4.1666666666666664e-02f + z * (-1.3888888888888889e-03f + z * (2.4801587301587302e-05f + z * -2.7557319223985888e-07f));
+    float hz = 0.5f * z;
+    return 1.0f - (hz - (z * z) * p);
+}
+
+/* returns quadrant (n mod 4) and writes the reduced argument */
+RT_HD int rt__rem_pio2(float x, float *r_out)
+{
+    const float TWO_OVER_PI = 0.6366197466850281f;        /* 0x3f22f983 */
+    const float P1 = 1.570556640625f;                     /* 0x3fc90800, 13 bits */
+    const float P2 = 0.0002396702766418457f;              /* 0x397b5000, 13 bits */
+    const float P3 = 1.5890691429376602e-08f;             /* 0x32888000 */
+    const float P4 = 2.5633440682570896e-12f;             /* 0x2c34611a */
+    const float MAGIC = 12582912.0f;                      /* 1.5 * 2^23: (t + MAGIC) - MAGIC = rint(t) */
+    uint32_t ax = rt_f2u(x) & 0x7fffffffu;
+    if (ax <= 0x3f490fdau) { *r_out = x; return 0; }      /* |x| <= pi/4 */
+    if (ax < 0x45490000u) {                               /* |x| < 3216: n <= 2048 */
+        float t = x * TWO_OVER_PI;
+        float fn = (t + MAGIC) - MAGIC;
+        float r = x - fn * P1;
+        r = r - fn * P2;
+        r = r - fn * P3;
+        r = r - fn * P4;
+        *r_out = r;
+        return (int)fn & 3;
+    }
+    if (ax >= 0x7f800000u) { *r_out = x - x; return 0; }  /* inf, NaN -> NaN */
+    {
+        const double D_TWO_OVER_PI = 0.6366197723675814;
+        const double D_HI = 1.5707963267341256;           /* 33 bits of pi/2 */
+        const double D_LO = 6.077100506506192e-11;
+        const double D_MAGIC = 6755399441055744.0;        /* 1.5 * 2^52 */
+        double xd = (double)x;
+        double dn = (xd * D_TWO_OVER_PI + D_MAGIC) - D_MAGIC;
+        double rd = (xd - dn * D_HI) - dn * D_LO;
+        *r_out = (float)rd;
+        /* dn can exceed int range for huge |x|: reduce mod 4 in binary64 first */
+        double q = dn * 0.25;
+        double qf = (q + D_MAGIC) - D_MAGIC;              /* rint(dn/4) */
+        int n4 = (int)(dn - 4.0 * qf);                    /* in [-2, 2] */
+        return n4 & 3;
+    }
+}
+
+RT_HD float rt_sinf(float x)
+{
+    float r;
+    int n = rt__rem_pio2(x, &r);
+    float s = (n & 1) ? rt__cos_k(r) : rt__sin_k(r);
+    return (n & 2) ? -s : s;
+}
+
+RT_HD float rt_cosf(float x)
+{
+    float r;
+    int n = rt__rem_pio2(x, &r);
+    float c = (n & 1) ? rt__sin_k(r) : rt__cos_k(r);
+    return ((n + 1) & 2) ? -c : c;
+}
+
+RT_HD float rt_tanf(float x) { return rt_sinf(x) / rt_cosf(x); }
+
+#endif /* RT_MATH_H */

@@ -1,0 +1,107 @@
+"""Scene descriptions: the BASELINE.json config scenes and the reference's
+own hard-coded demo scenes (reference src/main.cu:150-288), written as plain data.
+
+A description is a list of object tuples in list order (order matters: the later object wins
+distance ties, reference src/raytracer.cu:36):
+
+    ('sphere', center, radius, material)
+    ('triangle', p1, p2, p3, material)
+    ('triangle_uv', [p1,p2,p3], [uv1,uv2,uv3], material)
+    ('quad', p1, p2, p3, p4, material)
+    ('one_way_quad', p1, p2, p3, p4, invert_normal, material)
+    ('cuboid', tl_near_pos, width, height, depth, material)
+    ('mesh', triangles[n,9], material)
+    ('obj', filename, [('enlarge', s) | ('rotate', x, y, z) | ('translate', x, y, z), ...], material)
+
+and a material is ('standard', colour, smoothness) | ('emissive', colour, strength) |
+('checkerboard', light, dark, num_squares, smoothness) | ('gradient', smoothness) |
+('refractive', colour, n) — the arguments of the reference's Material::create_* /
+Texture::create_* factories (src/material.cu:21-51, :157-185).
+"""
+
+import numpy as np
+
+SKY_COLOUR = (0.8, 1.0, 1.0)          # reference src/main.cu:13
+NO_SKY = (0.0, 0.0, 0.0)              # reference src/main.cu:328
+
+
+def std(colour, smoothness):
+    return ("standard", tuple(colour), float(smoothness))
+
+
+def three_sphere():
+    """BASELINE configs[0], configs[1]; SURVEY.md App. C.1 'three-sphere'."""
+    return [
+        ("sphere", (0, -100.5, 1.5), 100, std((0.8, 0.8, 0.0), 0)),
+        ("sphere", (-0.6, 0, 1.5), 0.5, std((0.7, 0.3, 0.3), 0)),
+        ("sphere", (0.6, 0, 1.5), 0.5, std((0.3, 0.3, 0.7), 0)),
+    ], SKY_COLOUR
+
+
+def cube():
+    """BASELINE configs[2]; the rotation is mandatory (an axis-aligned cube loses faces to the
+    reference BVH's strict slab test)."""
+    return [
+        ("obj", "cube.obj", [("enlarge", 0.3), ("rotate", 0.4, 0.7, 0), ("translate", 0, 0, 1.8)], std((0.8, 0.4, 0.2), 0)),
+        ("sphere", (0, -100.5, 1.5), 100, std((0.5, 0.5, 0.5), 0)),
+    ], SKY_COLOUR
+
+
+def monkey():
+    """BASELINE configs[3], configs[4]; mesh transform = reference src/main.cu:157-160."""
+    return [
+        ("obj", "low_poly_monkey.obj", [("enlarge", 0.3), ("rotate", 0, 2.3, 0), ("translate", 0.1, -0.1, 1.6)], std((1, 1, 1), 0)),
+        ("sphere", (0, 1.2, 1.2), 0.5, ("emissive", (1, 1, 1), 6)),
+        ("sphere", (0, -100.5, 1.5), 100, std((0.5, 0.5, 0.5), 0.3)),
+    ], NO_SKY
+
+
+def _f(x):
+    return np.float32(x)
+
+
+def _add(a, b):
+    """Vec3 + Vec3 in float32, like the reference's host-side Vec3 arithmetic."""
+    return tuple(float(_f(x) + _f(y)) for x, y in zip(a, b))
+
+
+def _sub(a, b):
+    return tuple(float(_f(x) - _f(y)) for x, y in zip(a, b))
+
+
+def cornell_box(tl=(-0.5, 0.5, 1.2), width=1.0, height=1.0, depth=1.0, light_width=0.5):
+    """reference src/main.cu:252-288 (create_cornell_box); vector sums in float32, left to right."""
+    w, h, d = (width, 0, 0), (0, height, 0), (0, 0, depth)
+    floor = ("checkerboard", (0.1, 0.8, 0.1), (0.1, 0.5, 0.1), 8, 0)
+    objs = [
+        ("quad", _sub(tl, h), _add(_sub(tl, h), w), _add(_add(_sub(tl, h), w), d), _add(_sub(tl, h), d), floor),
+        ("quad", tl, _sub(tl, h), _add(_sub(tl, h), d), _add(tl, d), std((1, 0.2, 0.2), 0)),
+        ("quad", _add(tl, w), _sub(_add(tl, w), h), _add(_sub(_add(tl, w), h), d), _add(_add(tl, w), d), std((0.3, 0.3, 1), 0)),
+        ("quad", _add(tl, d), _add(_add(tl, w), d), _add(_sub(_add(tl, w), h), d), _add(_sub(tl, h), d), std((0.2, 0.2, 0.2), 0)),
+        ("quad", tl, _add(tl, d), _add(_add(tl, w), d), _add(tl, w), std((0.9, 0.9, 0.9), 0)),
+        ("one_way_quad", tl, _add(tl, w), _sub(_add(tl, w), h), _sub(tl, h), False, std((1, 1, 1), 0)),
+        ("cuboid", (float(_f(tl[0]) + _f(width) / _f(2) - _f(light_width) / _f(2)), tl[1],
+                    float(_f(tl[2]) + _f(depth) / _f(2) - _f(light_width) / _f(2))),
+         light_width, 0.04, light_width, ("emissive", (1, 1, 1), 6)),
+    ]
+    return objs
+
+
+def reference_scene0():
+    """reference src/main.cu:150-170 (monkey_test_scene)."""
+    objs = cornell_box()
+    objs.append(("obj", "low_poly_monkey.obj", [("enlarge", 0.3), ("rotate", 0, 2.3, 0), ("translate", 0.1, -0.1, 1.6)], std((1, 1, 1), 0)))
+    objs.append(("sphere", (-0.25, -0.25, 1.95), 0.25, std((0.8, 0.8, 0.8), 1)))
+    return objs, NO_SKY
+
+
+def reference_scene1():
+    """reference src/main.cu:172-187 (reflection_test_scene)."""
+    objs = cornell_box()
+    for c, s in (((-0.2, 0.2, 1.7), 0), ((0.2, 0.2, 1.7), 0.33), ((-0.2, -0.2, 1.7), 0.66), ((0.2, -0.2, 1.7), 1)):
+        objs.append(("sphere", c, 0.15, std((1, 1, 1), s)))
+    return objs, NO_SKY
+
+
+CONFIG_SCENES = {"three_sphere": three_sphere, "cube": cube, "monkey": monkey,
+                 "reference_scene0": reference_scene0, "reference_scene1": reference_scene1}
