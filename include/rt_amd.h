@@ -1,0 +1,196 @@
+/*
+ * rt_amd.h — C ABI of the MI355X path tracer (libraytracer_amd.so).
+ *
+ * The reference (Ben-Edwards44/Ray-Tracer) has no FFI; the seam its hot path sits behind is
+ * the host<->device edge in src/dispatch.cu plus three __constant__ uploads.  Each entry
+ * point below names the reference interface it replaces (file:line relative to the
+ * reference checkout).  Plain pointers and sizes only; nothing throws across this boundary:
+ * every call returns an rt_status and leaves a message for rt_last_error().
+ *
+ * Threading: one rt_ctx per GPU, used from one host thread at a time (the reference is a
+ * single host thread with blocking launches, src/dispatch.cu:139-141).  There are no hidden
+ * globals: scene, camera and settings are arguments (the reference's __constant__ symbols
+ * make it non-reentrant).
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t rt_status;
+enum {
+    RT_OK = 0,
+    RT_ERR_INVALID = 1,      /* bad argument */
+    RT_ERR_IO = 2,           /* "Could not find file to open."  (src/obj_read.cu:10) */
+    RT_ERR_UNSUPPORTED = 3,  /* e.g. "Only triangle or quad meshes are supported." (src/main.cu:141) */
+    RT_ERR_HIP = 4,          /* "Error from HIP (<what>): <hipGetErrorString>"  (src/utils.cu:5-10) */
+    RT_ERR_NOMEM = 5,
+    RT_ERR_NO_DEVICE = 6     /* the HIP runtime reports no usable GPU: there is NO CPU fallback */
+};
+
+typedef struct rt_ctx rt_ctx;
+typedef struct rt_scene rt_scene;
+typedef struct rt_scene_builder rt_scene_builder;
+typedef struct rt_obj rt_obj;
+
+/* ---- materials: Texture / Material, src/material.cu:4-186 ------------------------------- */
+enum { RT_TEX_COLOUR = 0, RT_TEX_GRADIENT = 1, RT_TEX_CHECKERBOARD = 2, RT_TEX_IMAGE = 3 };   /* :7-10 */
+enum { RT_MAT_STANDARD = 0, RT_MAT_EMISSIVE = 1, RT_MAT_REFRACTIVE = 2 };                     /* :131-133 */
+
+typedef struct rt_material {
+    int32_t type;              /* RT_MAT_* */
+    int32_t tex_type;          /* RT_TEX_* */
+    float colour[3];           /* Texture::create_const_colour :21-26 */
+    float light[3], dark[3];   /* Texture::create_checkerboard :32-40 */
+    int32_t num_squares;
+    float smoothness;          /* [0,1]: 0 diffuse, 1 mirror ("metal" = STANDARD with smoothness > 0) */
+    int32_t need_uv;
+    float emitted_light[3];    /* colour * strength, :170 */
+    float refractive_index;
+} rt_material;
+
+/* Material::create_standard(Texture::create_const_colour(colour), smoothness)  :157-165 */
+void rt_material_standard(rt_material *m, const float colour[3], float smoothness);
+/* Material::create_standard(Texture::create_checkerboard(light, dark, n), smoothness) */
+void rt_material_checkerboard(rt_material *m, const float light[3], const float dark[3], int32_t num_squares, float smoothness);
+/* Material::create_standard(Texture::create_gradient(), smoothness) */
+void rt_material_gradient(rt_material *m, float smoothness);
+/* Material::create_emissive(colour, strength) :167-173.  The reference leaves smoothness,
+ * need_uv and texture uninitialised there; this ABI defines them as 0 / false / COLOUR(0,0,0). */
+void rt_material_emissive(rt_material *m, const float colour[3], float strength);
+
+/* ---- scene: Object::create_* src/objects.cu:845-906, SceneObjects src/main.cu:94-296 ------ */
+rt_status rt_scene_builder_create(rt_scene_builder **out);
+void rt_scene_builder_destroy(rt_scene_builder *b);
+const char *rt_scene_builder_error(const rt_scene_builder *b);
+/* objects are kept in call order = the reference's std::vector<Object> order (ties go to
+ * the later object, src/raytracer.cu:36) */
+rt_status rt_scene_add_sphere(rt_scene_builder *b, const float center[3], float radius, const rt_material *m);          /* :845-852 */
+rt_status rt_scene_add_triangle(rt_scene_builder *b, const float p1[3], const float p2[3], const float p3[3], const rt_material *m);  /* :854-861 */
+rt_status rt_scene_add_triangle_uv(rt_scene_builder *b, const float p[9], const float uv[6], const rt_material *m);    /* :863-870 */
+rt_status rt_scene_add_quad(rt_scene_builder *b, const float p1[3], const float p2[3], const float p3[3], const float p4[3], const rt_material *m);  /* :872-879 */
+rt_status rt_scene_add_one_way_quad(rt_scene_builder *b, const float p1[3], const float p2[3], const float p3[3], const float p4[3], int32_t invert_normal, const rt_material *m);  /* :881-888 */
+rt_status rt_scene_add_cuboid(rt_scene_builder *b, const float tl_near_pos[3], float width, float height, float depth, const rt_material *m);  /* :890-897 */
+/* Object::create_mesh :899-906 — triangles: n*9 floats; the fixed-depth-10 BVH of
+ * src/objects.cu:602-719 is rebuilt host-side and stored compactly */
+rt_status rt_scene_add_mesh(rt_scene_builder *b, const float *triangles, int32_t n, const rt_material *m);
+/* SceneObjects::create_mesh src/main.cu:127-148 — faces of a loaded .obj (3 or 4 vertices) */
+rt_status rt_scene_add_obj_mesh(rt_scene_builder *b, const rt_obj *o, const rt_material *m);
+int32_t rt_scene_builder_num_objects(const rt_scene_builder *b);
+
+/* ---- .obj loader: ObjFileMesh src/obj_read.cu:47-147 ------------------------------------- */
+rt_status rt_obj_load(const char *filename, rt_obj **out);          /* ObjFileMesh(filename) :52-57 */
+void rt_obj_destroy(rt_obj *o);
+void rt_obj_enlarge(rt_obj *o, float scale_fact);                   /* :59-64 */
+void rt_obj_rotate(rt_obj *o, float x_angle, float y_angle, float z_angle);   /* :66-76; sin/cos from rt_math.h */
+void rt_obj_translate(rt_obj *o, float dx, float dy, float dz);     /* :78-86 */
+int32_t rt_obj_num_vertices(const rt_obj *o);
+int32_t rt_obj_num_faces(const rt_obj *o);
+int32_t rt_obj_face_arity(const rt_obj *o, int32_t face);
+void rt_obj_get_face(const rt_obj *o, int32_t face, int32_t *out /* arity 0-based vertex indices */);
+/* the same object from arrays already in memory: vertices n*3 floats, faces as a flat 0-based
+ * index list with one arity per face */
+rt_status rt_obj_from_arrays(const float *vertices, int32_t num_vertices, const int32_t *face_indices,
+                             const int32_t *face_arity, int32_t num_faces, rt_obj **out);
+void rt_obj_get_vertices(const rt_obj *o, float *out /* num_vertices*3 */);
+int32_t rt_obj_num_triangles(const rt_obj *o);                       /* after the quad split; -1 if a face is not 3/4-sided */
+rt_status rt_obj_get_triangles(const rt_obj *o, float *out /* num_triangles*9 */);
+
+/* ---- camera: src/camera.cu:12-21 (DeviceCamData) and :34-108 (Camera) -------------------- */
+typedef struct rt_camera {
+    float cam_pos[3];
+    float tl_pixel_pos[3];
+    float delta_u[3];
+    float delta_v[3];
+    int32_t width, height;     /* SCREEN_WIDTH / SCREEN_HEIGHT src/camera.cu:4-5, a parameter here */
+} rt_camera;
+
+/* Camera::assign_constant_mem :46-60 with the reference's pose constants (:34-41: origin,
+ * FOV 60 deg, focal length 0.1, no rotation); tan/sin/cos from rt_math.h */
+void rt_camera_default(int32_t width, int32_t height, rt_camera *out);
+/* same with pose parameters (angles in radians, rotation order Rx*Ry*Rz as :63-69) */
+void rt_camera_make(int32_t width, int32_t height, const float pos[3], float fov, float focal_len,
+                    float x_rot, float y_rot, float z_rot, rt_camera *out);
+
+/* ---- render settings: RenderData src/raytracer.cu:4-12 ----------------------------------- */
+typedef struct rt_render_settings {
+    int32_t rays_per_pixel;
+    int32_t reflection_limit;
+    int32_t antialias;
+    float sky_colour[3];
+} rt_render_settings;
+
+/* ---- context + scene upload -------------------------------------------------------------- */
+/* fails with RT_ERR_NO_DEVICE when HIP has no device: the product has no CPU path */
+rt_status rt_ctx_create(int32_t device, rt_ctx **out);
+void rt_ctx_destroy(rt_ctx *ctx);
+const char *rt_last_error(const rt_ctx *ctx);
+/* replaces create_gpu_struct src/main.cu:290-295 + allocate_constant_mem src/dispatch.cu:104-108:
+ * flattens the builder's objects into the compact device layout and uploads it */
+rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_scene **out);
+void rt_scene_destroy(rt_scene *s);
+/* introspection for tests: bytes staged in LDS per workgroup, node / triangle counts */
+typedef struct rt_scene_info {
+    int32_t num_objects, num_triangles, num_nodes, lds_bytes, scene_in_lds, threads_per_block;
+} rt_scene_info;
+rt_status rt_scene_get_info(const rt_scene *s, rt_scene_info *out);
+
+/* ---- the per-frame call: render() src/dispatch.cu:156-163 --------------------------------- */
+/* Host-buffer form, same contract as the reference: previous_render (W*H*3 floats, row-major
+ * interleaved RGB) is read, blended as (colour + prev*frame_num)/(frame_num+1)
+ * (src/raytracer.cu:109-112) and overwritten; *frame_num is incremented.  time_ms is the seed
+ * term the reference takes from the wall clock (src/main.cu:18-25). */
+rt_status rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
+                    int32_t time_ms, int32_t *frame_num, float *previous_render);
+
+/* Device-buffer form for callers that own HBM (PyTorch tensors) and streams.
+ * Rows are handed out in bands of `band_rows` rows; this call renders the bands whose index b
+ * satisfies b % band_stride == band_first (band_stride = number of GPUs, band_first = rank).
+ * d_prev (nullable = zeros) is always a full W*H*3 frame.  If compact == 0, d_out is a full
+ * frame and only the owned rows are written; if compact != 0, d_out holds the owned bands
+ * back to back (band k of this rank at row k*band_rows), which is the shape an all-gather wants.
+ * The launch is asynchronous on `hip_stream` (a hipStream_t, NULL = default stream). */
+typedef struct rt_tile_spec {
+    int32_t band_rows;       /* > 0, multiple of 8 */
+    int32_t band_first;
+    int32_t band_stride;
+    int32_t compact;
+} rt_tile_spec;
+
+rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
+                           int32_t time_ms, int32_t frame_num, const rt_tile_spec *tiles,
+                           const float *d_prev, float *d_out, void *hip_stream);
+/* number of rows a rank owns under a tile spec (host helper for sizing compact buffers) */
+int32_t rt_tile_owned_rows(const rt_tile_spec *tiles, int32_t height);
+
+/* Kernel timing by HIP events recorded on the launch stream around the render kernel of the
+ * most recent rt_render / rt_render_device call; blocks until that kernel has finished. */
+rt_status rt_last_kernel_ms(rt_ctx *ctx, float *ms);
+
+/* float -> RGBA8 display conversion of src/main.cu:343-371 (int(px*255), clamp, alpha 255),
+ * on the device: d_rgb W*H*3 floats -> d_rgba W*H*4 bytes */
+rt_status rt_to_rgba8_device(rt_ctx *ctx, const float *d_rgb, int32_t width, int32_t height, uint8_t *d_rgba, void *hip_stream);
+
+/* ---- introspection (tests only): the flattened device layout of a builder ---------------- */
+/* Pointers stay valid until the next rt_debug_flatten call on the same builder or its
+ * destruction.  blob is the LDS-staged part in 16-byte units (see
+ * ray-tracer_amd/csrc/rt_device_scene.h); objects is the scalar-loaded object table. */
+typedef struct rt_flat_view {
+    const float *blob; int32_t blob_f4;
+    int32_t off_nodes, off_tris, off_objlds;
+    const void *objects; int32_t num_objects, object_stride;
+    const float *tri_uv; int32_t num_triangles, num_nodes, has_mesh;
+} rt_flat_view;
+rt_status rt_debug_flatten(rt_scene_builder *b, rt_flat_view *out);
+
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

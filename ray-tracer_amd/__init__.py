@@ -1,0 +1,532 @@
+"""ray-tracer_amd — host-side Python mirror of the reference's scene / camera / render
+interface over the C ABI of libraytracer_amd.so (include/rt_amd.h).
+
+Import with ``importlib.import_module("ray-tracer_amd")`` (the directory name has a hyphen).
+
+The names follow the reference: ``Material.create_standard`` (src/material.cu:157),
+``Object``-style factories on :class:`SceneObjects` (src/objects.cu:845-906),
+:class:`ObjFileMesh` (src/obj_read.cu:47), :class:`Camera` (src/camera.cu:32),
+:class:`RenderData` (src/raytracer.cu:4), :class:`VariableRenderData` + :func:`render`
+(src/dispatch.cu:111-163).  All compute happens in the HIP library; there is no CPU path:
+creating a :class:`Context` without a GPU raises.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+from . import build as _build
+from . import scenes  # noqa: F401  (re-exported)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+RT_OK, RT_ERR_INVALID, RT_ERR_IO, RT_ERR_UNSUPPORTED, RT_ERR_HIP, RT_ERR_NOMEM, RT_ERR_NO_DEVICE = range(7)
+TEX_COLOUR, TEX_GRADIENT, TEX_CHECKERBOARD, TEX_IMAGE = 0, 1, 2, 3
+MAT_STANDARD, MAT_EMISSIVE, MAT_REFRACTIVE = 0, 1, 2
+
+
+class rt_material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("tex_type", C.c_int32), ("colour", C.c_float * 3),
+                ("light", C.c_float * 3), ("dark", C.c_float * 3), ("num_squares", C.c_int32),
+                ("smoothness", C.c_float), ("need_uv", C.c_int32), ("emitted_light", C.c_float * 3),
+                ("refractive_index", C.c_float)]
+
+
+class rt_camera(C.Structure):
+    _fields_ = [("cam_pos", C.c_float * 3), ("tl_pixel_pos", C.c_float * 3), ("delta_u", C.c_float * 3),
+                ("delta_v", C.c_float * 3), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class rt_render_settings(C.Structure):
+    _fields_ = [("rays_per_pixel", C.c_int32), ("reflection_limit", C.c_int32), ("antialias", C.c_int32),
+                ("sky_colour", C.c_float * 3)]
+
+
+class rt_tile_spec(C.Structure):
+    _fields_ = [("band_rows", C.c_int32), ("band_first", C.c_int32), ("band_stride", C.c_int32), ("compact", C.c_int32)]
+
+
+class rt_scene_info(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("num_objects", "num_triangles", "num_nodes", "lds_bytes", "scene_in_lds", "threads_per_block")]
+
+
+class rt_flat_view(C.Structure):
+    _fields_ = [("blob", C.POINTER(C.c_float)), ("blob_f4", C.c_int32), ("off_nodes", C.c_int32),
+                ("off_tris", C.c_int32), ("off_objlds", C.c_int32), ("objects", C.c_void_p),
+                ("num_objects", C.c_int32), ("object_stride", C.c_int32), ("tri_uv", C.POINTER(C.c_float)),
+                ("num_triangles", C.c_int32), ("num_nodes", C.c_int32), ("has_mesh", C.c_int32)]
+
+
+# every symbol include/rt_amd.h declares (tests/test_abi.py checks the .so exports them all)
+ABI_SYMBOLS = [
+    "rt_material_standard", "rt_material_checkerboard", "rt_material_gradient", "rt_material_emissive",
+    "rt_scene_builder_create", "rt_scene_builder_destroy", "rt_scene_builder_error", "rt_scene_add_sphere",
+    "rt_scene_add_triangle", "rt_scene_add_triangle_uv", "rt_scene_add_quad", "rt_scene_add_one_way_quad",
+    "rt_scene_add_cuboid", "rt_scene_add_mesh", "rt_scene_add_obj_mesh", "rt_scene_builder_num_objects",
+    "rt_obj_load", "rt_obj_destroy", "rt_obj_enlarge", "rt_obj_rotate", "rt_obj_translate",
+    "rt_obj_num_vertices", "rt_obj_num_faces", "rt_obj_face_arity", "rt_obj_get_face", "rt_obj_from_arrays", "rt_obj_get_vertices",
+    "rt_obj_num_triangles", "rt_obj_get_triangles", "rt_camera_default", "rt_camera_make",
+    "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_commit", "rt_scene_destroy",
+    "rt_scene_get_info", "rt_render", "rt_render_device", "rt_tile_owned_rows", "rt_last_kernel_ms",
+    "rt_to_rgba8_device", "rt_debug_flatten", "rt_version",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libraytracer_amd.so (building it with hipcc if the sources are newer).  Raises if
+    the HIP extension cannot be built or loaded: there is no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.build()
+    # PyTorch-ROCm bundles its own libamdhip64.so.7.  Two HIP runtimes in one process cannot
+    # both own the GPU, so when torch is installed it is imported first and this library then
+    # binds (by SONAME) to the runtime torch already loaded; device pointers and streams are
+    # then shared.  RT_AMD_NO_TORCH=1 skips this (pure ctypes use against /opt/rocm).
+    if "torch" not in sys.modules and os.environ.get("RT_AMD_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+    L = C.CDLL(path)
+    fp = C.POINTER(C.c_float)
+    vp = C.c_void_p
+    pm = C.POINTER(rt_material)
+    L.rt_material_standard.argtypes = [pm, fp, C.c_float]
+    L.rt_material_checkerboard.argtypes = [pm, fp, fp, C.c_int32, C.c_float]
+    L.rt_material_gradient.argtypes = [pm, C.c_float]
+    L.rt_material_emissive.argtypes = [pm, fp, C.c_float]
+    for n in ("rt_material_standard", "rt_material_checkerboard", "rt_material_gradient", "rt_material_emissive"):
+        getattr(L, n).restype = None
+    L.rt_scene_builder_create.argtypes = [C.POINTER(vp)]
+    L.rt_scene_builder_destroy.argtypes = [vp]
+    L.rt_scene_builder_destroy.restype = None
+    L.rt_scene_builder_error.argtypes = [vp]
+    L.rt_scene_builder_error.restype = C.c_char_p
+    L.rt_scene_add_sphere.argtypes = [vp, fp, C.c_float, pm]
+    L.rt_scene_add_triangle.argtypes = [vp, fp, fp, fp, pm]
+    L.rt_scene_add_triangle_uv.argtypes = [vp, fp, fp, pm]
+    L.rt_scene_add_quad.argtypes = [vp, fp, fp, fp, fp, pm]
+    L.rt_scene_add_one_way_quad.argtypes = [vp, fp, fp, fp, fp, C.c_int32, pm]
+    L.rt_scene_add_cuboid.argtypes = [vp, fp, C.c_float, C.c_float, C.c_float, pm]
+    L.rt_scene_add_mesh.argtypes = [vp, fp, C.c_int32, pm]
+    L.rt_scene_add_obj_mesh.argtypes = [vp, vp, pm]
+    L.rt_scene_builder_num_objects.argtypes = [vp]
+    L.rt_obj_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.rt_obj_destroy.argtypes = [vp]
+    L.rt_obj_destroy.restype = None
+    L.rt_obj_enlarge.argtypes = [vp, C.c_float]
+    L.rt_obj_rotate.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+    L.rt_obj_translate.argtypes = [vp, C.c_float, C.c_float, C.c_float]
+    for n in ("rt_obj_enlarge", "rt_obj_rotate", "rt_obj_translate"):
+        getattr(L, n).restype = None
+    for n in ("rt_obj_num_vertices", "rt_obj_num_faces", "rt_obj_num_triangles"):
+        getattr(L, n).argtypes = [vp]
+    L.rt_obj_face_arity.argtypes = [vp, C.c_int32]
+    L.rt_obj_get_face.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32)]
+    L.rt_obj_get_face.restype = None
+    L.rt_obj_from_arrays.argtypes = [fp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
+    L.rt_obj_get_vertices.argtypes = [vp, fp]
+    L.rt_obj_get_vertices.restype = None
+    L.rt_obj_get_triangles.argtypes = [vp, fp]
+    L.rt_camera_default.argtypes = [C.c_int32, C.c_int32, C.POINTER(rt_camera)]
+    L.rt_camera_default.restype = None
+    L.rt_camera_make.argtypes = [C.c_int32, C.c_int32, fp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(rt_camera)]
+    L.rt_camera_make.restype = None
+    L.rt_ctx_create.argtypes = [C.c_int32, C.POINTER(vp)]
+    L.rt_ctx_destroy.argtypes = [vp]
+    L.rt_ctx_destroy.restype = None
+    L.rt_last_error.argtypes = [vp]
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_scene_commit.argtypes = [vp, vp, C.POINTER(vp)]
+    L.rt_scene_destroy.argtypes = [vp]
+    L.rt_scene_destroy.restype = None
+    L.rt_scene_get_info.argtypes = [vp, C.POINTER(rt_scene_info)]
+    L.rt_render.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.c_int32, C.POINTER(C.c_int32), fp]
+    L.rt_render_device.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.c_int32, C.c_int32,
+                                   C.POINTER(rt_tile_spec), vp, vp, vp]
+    L.rt_tile_owned_rows.argtypes = [C.POINTER(rt_tile_spec), C.c_int32]
+    L.rt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.rt_to_rgba8_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
+    L.rt_debug_flatten.argtypes = [vp, C.POINTER(rt_flat_view)]
+    L.rt_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+class RayTracerError(RuntimeError):
+    """std::runtime_error of the reference (check_cuda_error src/utils.cu:5-10, read_file src/obj_read.cu:10)."""
+
+
+class UnsupportedMeshError(ValueError):
+    """std::logic_error("Only triangle or quad meshes are supported.") src/main.cu:141"""
+
+
+def _fp(a):
+    arr = np.ascontiguousarray(a, dtype=np.float32)
+    return arr, arr.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class Material:
+    """Material + Texture factories, reference src/material.cu:21-51, :157-185."""
+
+    def __init__(self, c_struct):
+        self.c = c_struct
+
+    @staticmethod
+    def create_standard(colour, smoothness):
+        m = rt_material()
+        lib().rt_material_standard(C.byref(m), _fp(colour)[1], C.c_float(smoothness))
+        return Material(m)
+
+    @staticmethod
+    def create_checkerboard(light, dark, num_squares, smoothness):
+        m = rt_material()
+        lib().rt_material_checkerboard(C.byref(m), _fp(light)[1], _fp(dark)[1], int(num_squares), C.c_float(smoothness))
+        return Material(m)
+
+    @staticmethod
+    def create_gradient(smoothness):
+        m = rt_material()
+        lib().rt_material_gradient(C.byref(m), C.c_float(smoothness))
+        return Material(m)
+
+    @staticmethod
+    def create_emissive(colour, strength):
+        m = rt_material()
+        lib().rt_material_emissive(C.byref(m), _fp(colour)[1], C.c_float(strength))
+        return Material(m)
+
+    @staticmethod
+    def from_desc(desc):
+        kind = desc[0]
+        if kind == "standard":
+            return Material.create_standard(desc[1], desc[2])
+        if kind == "emissive":
+            return Material.create_emissive(desc[1], desc[2])
+        if kind == "checkerboard":
+            return Material.create_checkerboard(desc[1], desc[2], desc[3], desc[4])
+        if kind == "gradient":
+            return Material.create_gradient(desc[1])
+        if kind == "refractive":
+            m = rt_material()
+            m.type = MAT_REFRACTIVE
+            m.colour[:] = [float(x) for x in desc[1]]
+            m.refractive_index = float(desc[2])
+            m.smoothness = 1.0
+            return Material(m)
+        raise ValueError(kind)
+
+
+class ObjFileMesh:
+    """reference src/obj_read.cu:47-147"""
+
+    def __init__(self, filename, _handle=None):
+        if _handle is not None:
+            self._h = _handle
+            return
+        h = C.c_void_p()
+        st = lib().rt_obj_load(os.fsencode(filename), C.byref(h))
+        if st == RT_ERR_IO:
+            raise RayTracerError("Could not find file to open.")
+        if st != RT_OK:
+            raise RayTracerError("could not parse %s" % filename)
+        self._h = h
+
+    @staticmethod
+    def from_arrays(vertices, faces):
+        """vertices [n,3] float32; faces: list of 0-based index lists"""
+        v, vp_ = _fp(np.asarray(vertices, np.float32).reshape(-1, 3))
+        flat = np.ascontiguousarray([i for f in faces for i in f], dtype=np.int32)
+        arity = np.ascontiguousarray([len(f) for f in faces], dtype=np.int32)
+        h = C.c_void_p()
+        st = lib().rt_obj_from_arrays(vp_, v.shape[0], flat.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      arity.ctypes.data_as(C.POINTER(C.c_int32)), len(faces), C.byref(h))
+        if st != RT_OK:
+            raise ValueError("bad mesh arrays")
+        return ObjFileMesh(None, _handle=h)
+
+    def faces(self):
+        out = []
+        for i, a in enumerate(self.face_arities()):
+            buf = (C.c_int32 * a)()
+            lib().rt_obj_get_face(self._h, i, buf)
+            out.append(list(buf))
+        return out
+
+    def enlarge(self, scale_fact):
+        lib().rt_obj_enlarge(self._h, C.c_float(scale_fact))
+
+    def rotate(self, x_angle, y_angle, z_angle):
+        lib().rt_obj_rotate(self._h, C.c_float(x_angle), C.c_float(y_angle), C.c_float(z_angle))
+
+    def translate(self, offset_x, offset_y, offset_z):
+        lib().rt_obj_translate(self._h, C.c_float(offset_x), C.c_float(offset_y), C.c_float(offset_z))
+
+    @property
+    def num_vertices(self):
+        return lib().rt_obj_num_vertices(self._h)
+
+    @property
+    def num_faces(self):
+        return lib().rt_obj_num_faces(self._h)
+
+    def face_arities(self):
+        return [lib().rt_obj_face_arity(self._h, i) for i in range(self.num_faces)]
+
+    def vertices(self):
+        out = np.empty((self.num_vertices, 3), np.float32)
+        lib().rt_obj_get_vertices(self._h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def triangles(self):
+        n = lib().rt_obj_num_triangles(self._h)
+        if n < 0:
+            raise UnsupportedMeshError("Only triangle or quad meshes are supported.\n")
+        out = np.empty((n, 9), np.float32)
+        lib().rt_obj_get_triangles(self._h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rt_obj_destroy(self._h)
+            self._h = None
+
+
+class SceneObjects:
+    """The object list of a scene: reference SceneObjects src/main.cu:94-296 with the
+    Object::create_* factories of src/objects.cu:845-906 as methods."""
+
+    def __init__(self, description=None, models_dir=None):
+        h = C.c_void_p()
+        if lib().rt_scene_builder_create(C.byref(h)) != RT_OK:
+            raise MemoryError()
+        self._h = h
+        self.models_dir = models_dir or scenes.models_dir()
+        if description:
+            self.add_description(description)
+
+    def _check(self, st):
+        if st == RT_OK:
+            return
+        msg = lib().rt_scene_builder_error(self._h).decode()
+        if st == RT_ERR_UNSUPPORTED and "triangle or quad" in msg:
+            raise UnsupportedMeshError(msg)
+        if st == RT_ERR_UNSUPPORTED:
+            raise NotImplementedError(msg)
+        raise ValueError(msg)
+
+    def create_sphere(self, center, radius, mat):
+        self._check(lib().rt_scene_add_sphere(self._h, _fp(center)[1], C.c_float(radius), C.byref(mat.c)))
+
+    def create_triangle(self, p1, p2, p3, mat, uv=None):
+        if uv is None:
+            self._check(lib().rt_scene_add_triangle(self._h, _fp(p1)[1], _fp(p2)[1], _fp(p3)[1], C.byref(mat.c)))
+        else:
+            pts = np.concatenate([np.asarray(p, np.float32).reshape(3) for p in (p1, p2, p3)])
+            self._check(lib().rt_scene_add_triangle_uv(self._h, _fp(pts)[1], _fp(np.asarray(uv).reshape(6))[1], C.byref(mat.c)))
+
+    def create_quad(self, p1, p2, p3, p4, mat):
+        self._check(lib().rt_scene_add_quad(self._h, _fp(p1)[1], _fp(p2)[1], _fp(p3)[1], _fp(p4)[1], C.byref(mat.c)))
+
+    def create_one_way_quad(self, p1, p2, p3, p4, invert_normal, mat):
+        self._check(lib().rt_scene_add_one_way_quad(self._h, _fp(p1)[1], _fp(p2)[1], _fp(p3)[1], _fp(p4)[1], int(bool(invert_normal)), C.byref(mat.c)))
+
+    def create_cuboid(self, tl_near_pos, width, height, depth, mat):
+        self._check(lib().rt_scene_add_cuboid(self._h, _fp(tl_near_pos)[1], C.c_float(width), C.c_float(height), C.c_float(depth), C.byref(mat.c)))
+
+    def create_mesh(self, mesh, mat):
+        """mesh: an ObjFileMesh (src/main.cu:127-148) or an array of triangles [n, 9]"""
+        if isinstance(mesh, ObjFileMesh):
+            self._check(lib().rt_scene_add_obj_mesh(self._h, mesh._h, C.byref(mat.c)))
+        else:
+            arr, p = _fp(np.asarray(mesh, np.float32).reshape(-1, 9))
+            self._check(lib().rt_scene_add_mesh(self._h, p, arr.shape[0], C.byref(mat.c)))
+
+    def add_description(self, description):
+        for o in description:
+            kind, mat = o[0], Material.from_desc(o[-1])
+            if kind == "sphere":
+                self.create_sphere(o[1], o[2], mat)
+            elif kind == "triangle":
+                self.create_triangle(o[1], o[2], o[3], mat)
+            elif kind == "triangle_uv":
+                p = np.asarray(o[1], np.float32).reshape(3, 3)
+                self.create_triangle(p[0], p[1], p[2], mat, uv=o[2])
+            elif kind == "quad":
+                self.create_quad(o[1], o[2], o[3], o[4], mat)
+            elif kind == "one_way_quad":
+                self.create_one_way_quad(o[1], o[2], o[3], o[4], o[5], mat)
+            elif kind == "cuboid":
+                self.create_cuboid(o[1], o[2], o[3], o[4], mat)
+            elif kind == "mesh":
+                self.create_mesh(o[1], mat)
+            elif kind == "obj":
+                path = o[1] if os.path.isabs(o[1]) else os.path.join(self.models_dir, o[1])
+                m = ObjFileMesh(path)
+                for t in o[2]:
+                    getattr(m, t[0])(*t[1:])
+                self.create_mesh(m, mat)
+            else:
+                raise ValueError(kind)
+
+    @property
+    def num_objects(self):
+        return lib().rt_scene_builder_num_objects(self._h)
+
+    def debug_flatten(self):
+        """The flattened device layout as numpy arrays (tests only)."""
+        v = rt_flat_view()
+        self._check(lib().rt_debug_flatten(self._h, C.byref(v)))
+        blob = np.ctypeslib.as_array(v.blob, shape=(v.blob_f4, 4)).copy() if v.blob_f4 else np.zeros((0, 4), np.float32)
+        raw = C.string_at(v.objects, v.num_objects * v.object_stride) if v.num_objects else b""
+        objs = np.frombuffer(raw, dtype=np.dtype([("type", "<i4"), ("prim_start", "<i4"), ("need_uv", "<i4"), ("root_ref", "<u4"), ("v", "<f4", (8,))]))
+        uv = np.ctypeslib.as_array(v.tri_uv, shape=(v.num_triangles, 6)).copy() if v.tri_uv else None
+        return {"blob": blob, "off_nodes": v.off_nodes, "off_tris": v.off_tris, "off_objlds": v.off_objlds,
+                "objects": objs, "tri_uv": uv, "num_triangles": v.num_triangles, "num_nodes": v.num_nodes,
+                "has_mesh": bool(v.has_mesh)}
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rt_scene_builder_destroy(self._h)
+            self._h = None
+
+
+class Camera:
+    """reference Camera src/camera.cu:32-108; ``assign_constant_mem`` becomes :attr:`c` (the
+    48-byte DeviceCamData plus the image size), passed to render calls."""
+
+    def __init__(self, width, height, pos=None, fov=None, focal_len=None, rot=(0.0, 0.0, 0.0), floats=None):
+        self.c = rt_camera()
+        if floats is not None:      # the 12 floats verbatim (fixtures)
+            f = np.asarray(floats, np.float32).reshape(12)
+            self.c.cam_pos[:] = f[0:3].tolist()
+            self.c.tl_pixel_pos[:] = f[3:6].tolist()
+            self.c.delta_u[:] = f[6:9].tolist()
+            self.c.delta_v[:] = f[9:12].tolist()
+            self.c.width, self.c.height = int(width), int(height)
+        elif pos is None and fov is None and focal_len is None and tuple(rot) == (0.0, 0.0, 0.0):
+            lib().rt_camera_default(int(width), int(height), C.byref(self.c))
+        else:
+            pi = np.float32(3.141592653589793)
+            fov = np.float32(60) * (pi / np.float32(180)) if fov is None else fov
+            lib().rt_camera_make(int(width), int(height), _fp(pos or (0, 0, 0))[1], C.c_float(fov),
+                                 C.c_float(0.1 if focal_len is None else focal_len),
+                                 C.c_float(rot[0]), C.c_float(rot[1]), C.c_float(rot[2]), C.byref(self.c))
+
+    @property
+    def width(self):
+        return self.c.width
+
+    @property
+    def height(self):
+        return self.c.height
+
+    def floats(self):
+        return np.array(list(self.c.cam_pos) + list(self.c.tl_pixel_pos) + list(self.c.delta_u) + list(self.c.delta_v), np.float32)
+
+
+class RenderData:
+    """reference RenderData src/raytracer.cu:4-12 (defaults of RenderSettings src/main.cu:318-330)"""
+
+    def __init__(self, rays_per_pixel=100, reflection_limit=5, antialias=True, sky_colour=(0.0, 0.0, 0.0)):
+        self.c = rt_render_settings(int(rays_per_pixel), int(reflection_limit), int(bool(antialias)), (C.c_float * 3)(*[float(x) for x in sky_colour]))
+
+
+class VariableRenderData:
+    """reference VariableRenderData src/dispatch.cu:111-115"""
+
+    def __init__(self, width, height):
+        self.frame_num = 0
+        self.previous_render = np.zeros((height, width, 3), np.float32)
+
+
+class Context:
+    """One per GPU.  Raises when there is no GPU (the product has no CPU path)."""
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        st = lib().rt_ctx_create(int(device), C.byref(h))
+        if st == RT_ERR_NO_DEVICE:
+            raise RayTracerError("Error from HIP (creating context): no usable GPU; ray-tracer_amd has no CPU fallback")
+        if st != RT_OK:
+            raise RayTracerError("Error from HIP (creating context): status %d" % st)
+        self._h = h
+        self.device = device
+
+    def _check(self, st):
+        if st != RT_OK:
+            msg = lib().rt_last_error(self._h).decode()
+            if st == RT_ERR_UNSUPPORTED:
+                raise NotImplementedError(msg)
+            if st == RT_ERR_INVALID:
+                raise ValueError(msg)
+            raise RayTracerError(msg)
+
+    def commit(self, scene_objects):
+        return Scene(self, scene_objects)
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._check(lib().rt_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rt_ctx_destroy(self._h)
+            self._h = None
+
+
+class Scene:
+    """A committed (uploaded) scene: replaces create_gpu_struct src/main.cu:290-295 +
+    allocate_constant_mem src/dispatch.cu:104-108."""
+
+    def __init__(self, ctx, scene_objects):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(lib().rt_scene_commit(ctx._h, scene_objects._h, C.byref(h)))
+        self._h = h
+
+    def info(self):
+        i = rt_scene_info()
+        self.ctx._check(lib().rt_scene_get_info(self._h, C.byref(i)))
+        return {n: getattr(i, n) for n, _ in i._fields_}
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rt_scene_destroy(self._h)
+            self._h = None
+
+
+def render(ctx, scene, camera, render_data, data, current_time_ms):
+    """reference render(VariableRenderData*, int) src/dispatch.cu:156-163: reads
+    data.previous_render, overwrites it with the new progressive average, increments
+    data.frame_num."""
+    fn = C.c_int32(data.frame_num)
+    buf = data.previous_render
+    assert buf.dtype == np.float32 and buf.flags["C_CONTIGUOUS"]
+    ctx._check(lib().rt_render(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), int(current_time_ms),
+                               C.byref(fn), buf.ctypes.data_as(C.POINTER(C.c_float))))
+    data.frame_num = fn.value
+    return buf
+
+
+def render_device(ctx, scene, camera, render_data, time_ms, frame_num, d_out, d_prev=None,
+                  band_rows=8, band_first=0, band_stride=1, compact=False, stream=None):
+    """Device-buffer form: d_out / d_prev are device pointers (ints, e.g. torch.Tensor.data_ptr())."""
+    ts = rt_tile_spec(int(band_rows), int(band_first), int(band_stride), int(bool(compact)))
+    ctx._check(lib().rt_render_device(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), int(time_ms), int(frame_num),
+                                      C.byref(ts), C.c_void_p(d_prev or 0), C.c_void_p(d_out), C.c_void_p(stream or 0)))
+
+
+def tile_owned_rows(height, band_rows=8, band_first=0, band_stride=1):
+    ts = rt_tile_spec(int(band_rows), int(band_first), int(band_stride), 0)
+    return lib().rt_tile_owned_rows(C.byref(ts), int(height))
+
+
+def to_rgba8_device(ctx, d_rgb, width, height, d_rgba, stream=None):
+    """float -> RGBA8 of src/main.cu:343-371 on the device."""
+    ctx._check(lib().rt_to_rgba8_device(ctx._h, C.c_void_p(d_rgb), int(width), int(height), C.c_void_p(d_rgba), C.c_void_p(stream or 0)))

@@ -1,0 +1,294 @@
+/*
+ * rt_capi.cpp — the device half of the C ABI (include/rt_amd.h): context, scene upload,
+ * render launches, timing.  Replaces the reference's host<->device seam
+ * (src/dispatch.cu:104-163): where the reference allocates and frees four device buffers per
+ * frame and copies the frame element-wise out of managed memory, the context here keeps
+ * persistent HBM frame buffers and the device-buffer entry point takes caller-owned HBM.
+ *
+ * There is no CPU fallback: rt_ctx_create fails when HIP has no device.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "rt_host.h"
+
+extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh, int threads, int blocks, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t rt_launch_rgba8(const float *rgb, int n_pixels, uint8_t *out, hipStream_t stream);
+
+#define RT_LDS_LIMIT 163840   /* 160 KiB per CU / per workgroup on gfx950 */
+
+struct rt_ctx {
+    int device = 0;
+    int num_cus = 0;
+    std::string err;
+    uint32_t *tile_counter = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool have_timing = false;
+    /* persistent frame buffers for the host-buffer entry point */
+    float *d_prev = nullptr, *d_out = nullptr;
+    size_t frame_bytes = 0;
+};
+
+struct rt_scene {
+    rt_ctx *ctx = nullptr;
+    rt_f4 *d_blob = nullptr;
+    rt_object *d_objects = nullptr;
+    float *d_tri_uv = nullptr;
+    FlatScene flat;          /* host copy (sizes, offsets) */
+    int threads = 0;         /* workgroup size chosen for this scene */
+    size_t lds_bytes = 0;
+};
+
+namespace {
+
+/* check_cuda_error src/utils.cu:5-10 */
+rt_status hip_fail(rt_ctx *ctx, hipError_t e, const char *what)
+{
+    if (ctx) ctx->err = std::string("Error from HIP (") + what + "): " + hipGetErrorString(e);
+    return RT_ERR_HIP;
+}
+
+#define RT_HIP(ctx, call, what)                         \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, what); \
+    } while (0)
+
+rt_status set_err(rt_ctx *ctx, rt_status code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+}  // namespace
+
+extern "C" const char *rt_version(void) { return "ray-tracer_amd 0.1 (gfx950)"; }
+
+extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
+{
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return RT_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return RT_ERR_INVALID;
+    rt_ctx *ctx = new (std::nothrow) rt_ctx();
+    if (!ctx) return RT_ERR_NOMEM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return RT_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return RT_ERR_NO_DEVICE; }
+    ctx->num_cus = prop.multiProcessorCount;
+    if (hipMalloc((void **)&ctx->tile_counter, 256) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        rt_ctx_destroy(ctx);
+        return RT_ERR_HIP;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+extern "C" void rt_ctx_destroy(rt_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->tile_counter) (void)hipFree(ctx->tile_counter);
+    if (ctx->d_prev) (void)hipFree(ctx->d_prev);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    delete ctx;
+}
+
+extern "C" const char *rt_last_error(const rt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_scene **out)
+{
+    if (!ctx || !b || !out) return RT_ERR_INVALID;
+    *out = nullptr;
+    rt_scene *s = new (std::nothrow) rt_scene();
+    if (!s) return RT_ERR_NOMEM;
+    s->ctx = ctx;
+    std::string err = rt_flatten(*b, s->flat);
+    if (!err.empty()) { delete s; return set_err(ctx, RT_ERR_UNSUPPORTED, err); }
+
+    /* workgroup size: the largest one whose LDS (scene + per-lane traversal stacks) fits */
+    const size_t blob_bytes = s->flat.blob.size() * sizeof(rt_f4);
+    const size_t per_thread = s->flat.has_mesh ? (size_t)RT_STACK_ENTRIES * 8 : 0;
+    const int candidates[4] = {1024, 768, 512, 256};
+    s->threads = 0;
+    if (!s->flat.has_mesh) {
+        if (blob_bytes <= RT_LDS_LIMIT) { s->threads = 256; s->lds_bytes = blob_bytes; }
+    } else {
+        for (int nt : candidates) {
+            if (blob_bytes + per_thread * (size_t)nt <= RT_LDS_LIMIT) { s->threads = nt; s->lds_bytes = blob_bytes + per_thread * (size_t)nt; break; }
+        }
+    }
+    if (s->threads == 0) {
+        delete s;
+        return set_err(ctx, RT_ERR_UNSUPPORTED, "scene does not fit the 160 KiB LDS of a compute unit (" + std::to_string(blob_bytes) + " bytes)");
+    }
+
+    (void)hipSetDevice(ctx->device);
+    hipError_t e = hipMalloc((void **)&s->d_blob, blob_bytes > 0 ? blob_bytes : 16);
+    if (e == hipSuccess && blob_bytes) e = hipMemcpy(s->d_blob, s->flat.blob.data(), blob_bytes, hipMemcpyHostToDevice);
+    const size_t obj_bytes = s->flat.objects.size() * sizeof(rt_object);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_objects, obj_bytes > 0 ? obj_bytes : 16);
+    if (e == hipSuccess && obj_bytes) e = hipMemcpy(s->d_objects, s->flat.objects.data(), obj_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && !s->flat.tri_uv.empty()) {
+        e = hipMalloc((void **)&s->d_tri_uv, s->flat.tri_uv.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(s->d_tri_uv, s->flat.tri_uv.data(), s->flat.tri_uv.size() * 4, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) {
+        rt_scene_destroy(s);
+        return hip_fail(ctx, e, "uploading scene");
+    }
+    *out = s;
+    return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(rt_scene *s)
+{
+    if (!s) return;
+    if (s->ctx) (void)hipSetDevice(s->ctx->device);
+    if (s->d_blob) (void)hipFree(s->d_blob);
+    if (s->d_objects) (void)hipFree(s->d_objects);
+    if (s->d_tri_uv) (void)hipFree(s->d_tri_uv);
+    delete s;
+}
+
+extern "C" rt_status rt_scene_get_info(const rt_scene *s, rt_scene_info *out)
+{
+    if (!s || !out) return RT_ERR_INVALID;
+    out->num_objects = (int32_t)s->flat.objects.size();
+    out->num_triangles = s->flat.num_tris;
+    out->num_nodes = s->flat.num_nodes;
+    out->lds_bytes = (int32_t)s->lds_bytes;
+    out->scene_in_lds = 1;
+    out->threads_per_block = s->threads;
+    return RT_OK;
+}
+
+extern "C" int32_t rt_tile_owned_rows(const rt_tile_spec *t, int32_t height)
+{
+    if (!t || t->band_rows <= 0 || t->band_stride <= 0 || t->band_first < 0 || t->band_first >= t->band_stride) return -1;
+    int32_t bands_total = (height + t->band_rows - 1) / t->band_rows;
+    int32_t owned = bands_total > t->band_first ? (bands_total - t->band_first + t->band_stride - 1) / t->band_stride : 0;
+    return owned * t->band_rows;
+}
+
+extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
+                                      int32_t time_ms, int32_t frame_num, const rt_tile_spec *tiles,
+                                      const float *d_prev, float *d_out, void *hip_stream)
+{
+    if (!ctx || !scene || !cam || !rs || !d_out) return set_err(ctx, RT_ERR_INVALID, "null argument");
+    if (scene->ctx != ctx) return set_err(ctx, RT_ERR_INVALID, "scene belongs to another context");
+    if (cam->width <= 0 || cam->height <= 0 || (int64_t)cam->width * cam->height > (1 << 28)) return set_err(ctx, RT_ERR_INVALID, "bad image size");
+    if (rs->rays_per_pixel < 0 || rs->reflection_limit < 0) return set_err(ctx, RT_ERR_INVALID, "bad render settings");
+    rt_tile_spec full = {8, 0, 1, 0};
+    const rt_tile_spec *t = tiles ? tiles : &full;
+    if (t->band_rows <= 0 || (t->band_rows & 7) || t->band_stride <= 0 || t->band_first < 0 || t->band_first >= t->band_stride)
+        return set_err(ctx, RT_ERR_INVALID, "bad tile spec (band_rows must be a positive multiple of 8, 0 <= band_first < band_stride)");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+
+    rt_kernel_args a;
+    std::memset(&a, 0, sizeof a);
+    std::memcpy(a.cam + 0, cam->cam_pos, 12);
+    std::memcpy(a.cam + 3, cam->tl_pixel_pos, 12);
+    std::memcpy(a.cam + 6, cam->delta_u, 12);
+    std::memcpy(a.cam + 9, cam->delta_v, 12);
+    a.width = cam->width;
+    a.height = cam->height;
+    a.rays_per_pixel = rs->rays_per_pixel;
+    a.reflection_limit = rs->reflection_limit;
+    a.antialias = rs->antialias ? 1 : 0;
+    std::memcpy(a.sky, rs->sky_colour, 12);
+    a.seed_time = (uint32_t)time_ms * 6291469u;       /* src/raytracer.cu:127 */
+    a.frame_num = frame_num;
+    a.band_rows = t->band_rows;
+    a.band_first = t->band_first;
+    a.band_stride = t->band_stride;
+    a.compact = t->compact ? 1 : 0;
+    a.tiles_x = (cam->width + 7) / 8;
+    const int owned_rows = rt_tile_owned_rows(t, cam->height);
+    a.num_tiles = (owned_rows / 8) * a.tiles_x;
+    a.objects = scene->d_objects;
+    a.num_objects = (int32_t)scene->flat.objects.size();
+    a.blob = scene->d_blob;
+    a.blob_f4 = (int32_t)scene->flat.blob.size();
+    a.off_nodes = scene->flat.off_nodes;
+    a.off_tris = scene->flat.off_tris;
+    a.off_objlds = scene->flat.off_objlds;
+    a.tri_uv = scene->d_tri_uv;
+    a.prev = d_prev;
+    a.out = d_out;
+    a.tile_counter = ctx->tile_counter;
+
+    RT_HIP(ctx, hipEventRecord(ctx->ev_start, stream), "recording start event");
+    ctx->have_timing = false;
+    if (a.num_tiles > 0) {
+        /* persistent waves: enough workgroups to fill the chip, each wave pulls 8x8 tiles */
+        const int waves_per_block = scene->threads / 64;
+        int blocks_per_cu = scene->flat.has_mesh ? 1 : 4;
+        if (!scene->flat.has_mesh && scene->lds_bytes > 0) {
+            int by_lds = (int)(RT_LDS_LIMIT / scene->lds_bytes);
+            if (by_lds < blocks_per_cu) blocks_per_cu = by_lds < 1 ? 1 : by_lds;
+        }
+        int blocks = ctx->num_cus * blocks_per_cu;
+        int needed = (a.num_tiles + waves_per_block - 1) / waves_per_block;
+        if (blocks > needed) blocks = needed;
+        RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 4, stream), "clearing tile counter");
+        RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
+    }
+    RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream), "recording stop event");
+    ctx->have_timing = true;
+    return RT_OK;
+}
+
+extern "C" rt_status rt_last_kernel_ms(rt_ctx *ctx, float *ms)
+{
+    if (!ctx || !ms) return RT_ERR_INVALID;
+    if (!ctx->have_timing) return set_err(ctx, RT_ERR_INVALID, "no render has been launched yet");
+    RT_HIP(ctx, hipEventSynchronize(ctx->ev_stop), "waiting for render kernel");
+    RT_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop), "reading kernel time");
+    return RT_OK;
+}
+
+extern "C" rt_status rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
+                               int32_t time_ms, int32_t *frame_num, float *previous_render)
+{
+    if (!ctx || !cam || !frame_num || !previous_render) return set_err(ctx, RT_ERR_INVALID, "null argument");
+    if (cam->width <= 0 || cam->height <= 0) return set_err(ctx, RT_ERR_INVALID, "bad image size");
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    const size_t bytes = (size_t)cam->width * (size_t)cam->height * 3 * sizeof(float);
+    if (bytes != ctx->frame_bytes) {
+        if (ctx->d_prev) (void)hipFree(ctx->d_prev);
+        if (ctx->d_out) (void)hipFree(ctx->d_out);
+        ctx->d_prev = ctx->d_out = nullptr;
+        ctx->frame_bytes = 0;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_prev, bytes), "allocating previous-frame buffer");
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_out, bytes), "allocating frame buffer");
+        ctx->frame_bytes = bytes;
+    }
+    RT_HIP(ctx, hipMemcpy(ctx->d_prev, previous_render, bytes, hipMemcpyHostToDevice), "copying previous frame");
+    rt_status st = rt_render_device(ctx, scene, cam, rs, time_ms, *frame_num, nullptr, ctx->d_prev, ctx->d_out, nullptr);
+    if (st != RT_OK) return st;
+    RT_HIP(ctx, hipDeviceSynchronize(), "render kernel");
+    RT_HIP(ctx, hipMemcpy(previous_render, ctx->d_out, bytes, hipMemcpyDeviceToHost), "copying frame to host");
+    *frame_num += 1;                                   /* src/dispatch.cu:159 */
+    RT_HIP(ctx, hipPeekAtLastError(), "final check after render");   /* src/dispatch.cu:161-162 */
+    return RT_OK;
+}
+
+extern "C" rt_status rt_to_rgba8_device(rt_ctx *ctx, const float *d_rgb, int32_t width, int32_t height, uint8_t *d_rgba, void *hip_stream)
+{
+    if (!ctx || !d_rgb || !d_rgba || width <= 0 || height <= 0) return set_err(ctx, RT_ERR_INVALID, "bad argument");
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    RT_HIP(ctx, rt_launch_rgba8(d_rgb, width * height, d_rgba, (hipStream_t)hip_stream), "launching rgba8 kernel");
+    return RT_OK;
+}

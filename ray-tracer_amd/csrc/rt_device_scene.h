@@ -1,0 +1,100 @@
+/*
+ * rt_device_scene.h — the compact scene layout the HIP kernel reads, and the kernel argument
+ * block.  Written by the host flattener (rt_host.cpp), read by rt_kernel.hip.
+ *
+ * The reference keeps the scene as an array of 5,328-byte `Object` unions, 216-byte triangles
+ * and 3,616-byte BVH nodes with one device allocation per node (SURVEY.md §8 sizes).  Here:
+ *
+ *   LDS-staged blob (one coalesced copy per workgroup, 16-byte units):
+ *     nodes   64 B  both children's boxes + child references (one LDS round trip per step)
+ *     tris    48 B  p0, side1, side2, unit normal            (reference src/objects.cu:175-186)
+ *     objlds  48 B  per top-level object: what shading needs for a per-lane object index
+ *   global memory, read with wave-uniform (scalar) loads while looping over the object list:
+ *     objects 48 B  type, primitive range / BVH root, sphere or root-box constants
+ *   global memory, read once per textured hit:
+ *     tri_uv  24 B  per-triangle texture coordinates (only when a material needs UVs)
+ *
+ * The BVH is the reference's tree (fixed depth 10, same split order, same leaf order), with
+ * every node's box stored in its parent.  Empty subtrees collapse into an "empty leaf"
+ * reference whose stored box is the reference's (0,0,0)-(0,0,0) box, so the strict slab test
+ * treats them exactly as the reference does without a special case.
+ */
+#ifndef RT_DEVICE_SCENE_H
+#define RT_DEVICE_SCENE_H
+
+#include <stdint.h>
+
+#define RT_BVH_DEPTH 10              /* reference src/objects.cu:786 */
+#define RT_STACK_ENTRIES RT_BVH_DEPTH /* at most one pending sibling per level below the root */
+#define RT_INF_F 1073741824.0f       /* reference `1 << 31 - 1` == 1 << 30, src/objects.cu:6 */
+#define RT_EPS_F 0.000001f           /* FLOAT_PRECISION_ERROR src/objects.cu:7 */
+
+/* child / root references */
+#define RT_REF_LEAF 0x80000000u
+#define RT_REF_COUNT_SHIFT 20
+#define RT_REF_COUNT_MAX 2047u
+#define RT_REF_START_MASK 0x000fffffu
+#define RT_REF_EMPTY_LEAF RT_REF_LEAF          /* leaf with zero triangles */
+
+enum { RT_OBJ_SPHERE = 0, RT_OBJ_TRIANGLE = 1, RT_OBJ_QUAD = 2, RT_OBJ_ONE_WAY_QUAD = 3, RT_OBJ_CUBOID = 4, RT_OBJ_MESH = 5 };   /* src/objects.cu:804-809 */
+
+/* material tags as stored in rt_objlds.b.w bits [1:0] (reference src/material.cu:131-133) */
+#define RT_DEV_MAT_STANDARD 0
+#define RT_DEV_MAT_EMISSIVE 1
+#define RT_DEV_MAT_REFRACTIVE 2
+
+typedef struct { float x, y, z, w; } rt_f4;
+
+/* q0 = (lmin.x lmin.y lmin.z lmax.x) q1 = (lmax.y lmax.z rmin.x rmin.y) q2 = (rmin.z rmax.x rmax.y rmax.z)
+ * q3 = (lref, rref, 0, 0) as raw bits */
+typedef struct { rt_f4 q[4]; } rt_node;
+
+/* q0 = (p0.x p0.y p0.z s1.x) q1 = (s1.y s1.z s2.x s2.y) q2 = (s2.z n.x n.y n.z) */
+typedef struct { rt_f4 q[3]; } rt_tri;
+
+/* a = (A.rgb, smoothness): A = colour (COLOUR) or light (CHECKERBOARD)
+ * b = (B.rgb, packed): B = emitted light (EMISSIVE) or dark (CHECKERBOARD) ; B.x = refractive index (REFRACTIVE)
+ *     packed bits: [1:0] material type, [3:2] texture type, [4] need_uv, [5] is_sphere, [31:8] num_squares
+ * c = sphere (center.xyz, radius) */
+typedef struct { rt_f4 a, b, c; } rt_objlds;
+
+#define RT_PACK_MAT(type, tex, need_uv, is_sphere, nsq) \
+    ((uint32_t)(type) | ((uint32_t)(tex) << 2) | ((uint32_t)(need_uv) << 4) | ((uint32_t)(is_sphere) << 5) | ((uint32_t)(nsq) << 8))
+
+/* SPHERE: v = center.xyz, radius
+ * TRIANGLE / QUAD / CUBOID: prim_start = first triangle (1 / 2 / 12 of them)
+ * ONE_WAY_QUAD: v[0..2] = its normal (t1.normal * multiplier, src/objects.cu:285-289)
+ * MESH: root_ref, v[0..5] = root box min/max */
+typedef struct {
+    int32_t type;
+    int32_t prim_start;
+    int32_t need_uv;
+    uint32_t root_ref;
+    float v[8];
+} rt_object;
+
+typedef struct {
+    float cam[12];                 /* cam_pos, tl_pixel_pos, delta_u, delta_v  (src/camera.cu:12-21) */
+    int32_t width, height;
+    int32_t rays_per_pixel, reflection_limit, antialias;   /* RenderData src/raytracer.cu:4-12 */
+    float sky[3];
+    uint32_t seed_time;            /* (uint32)time_ms * 6291469  (src/raytracer.cu:127) */
+    int32_t frame_num;
+    /* tile assignment */
+    int32_t band_rows, band_first, band_stride, compact;
+    int32_t tiles_x;               /* 8x8 tiles per row of tiles */
+    int32_t num_tiles;             /* tiles this launch renders */
+    /* scene */
+    const rt_object *objects;
+    int32_t num_objects;
+    const rt_f4 *blob;             /* LDS-staged part */
+    int32_t blob_f4;               /* its size in 16-byte units */
+    int32_t off_nodes, off_tris, off_objlds;   /* section offsets in 16-byte units */
+    const float *tri_uv;           /* 6 floats per triangle, or NULL */
+    /* frame buffers */
+    const float *prev;             /* full frame or NULL */
+    float *out;
+    uint32_t *tile_counter;        /* zeroed before the launch */
+} rt_kernel_args;
+
+#endif

@@ -19,7 +19,49 @@ and a material is ('standard', colour, smoothness) | ('emissive', colour, streng
 Texture::create_* factories (src/material.cu:21-51, :157-185).
 """
 
+import os
+import tempfile
+
 import numpy as np
+
+_MODELS_NPZ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "models")
+_models_dir = None
+
+
+def write_obj(path, vertices, faces):
+    """Wavefront text the reference's loader accepts (src/obj_read.cu:92-147): `v x y z` lines
+    (%.9g round-trips float32), `vn`/`vt` lines it must ignore, 1-based `f i/j/k` faces."""
+    with open(path, "w") as f:
+        f.write("# written by ray-tracer_amd.scenes.write_obj\no mesh\n")
+        for v in np.asarray(vertices, np.float32):
+            f.write("v %.9g %.9g %.9g\n" % (v[0], v[1], v[2]))
+        f.write("vn 0.0000 1.0000 0.0000\nvt 0.500000 0.500000\ns 0\n")
+        for face in faces:
+            f.write("f " + " ".join("%d/1/1" % (i + 1) for i in face) + "\n")
+
+
+def load_model_arrays(name):
+    """(vertices[n,3] float32, faces as lists of 0-based indices) of a shipped model.  The
+    arrays were extracted from the reference's models/*.obj by tools/make_model_fixtures.py."""
+    z = np.load(os.path.join(_MODELS_NPZ, os.path.splitext(name)[0] + ".npz"))
+    faces, k = [], 0
+    for a in z["face_arity"]:
+        faces.append([int(i) for i in z["face_indices"][k:k + a]])
+        k += int(a)
+    return z["vertices"].astype(np.float32), faces
+
+
+def models_dir():
+    """A directory holding cube.obj and low_poly_monkey.obj, written from the shipped arrays."""
+    global _models_dir
+    if _models_dir is None or not os.path.isdir(_models_dir):
+        d = tempfile.mkdtemp(prefix="rt_amd_models_")
+        for name in ("cube", "low_poly_monkey"):
+            v, f = load_model_arrays(name)
+            write_obj(os.path.join(d, name + ".obj"), v, f)
+        _models_dir = d
+    return _models_dir
+
 
 SKY_COLOUR = (0.8, 1.0, 1.0)          # reference src/main.cu:13
 NO_SKY = (0.0, 0.0, 0.0)              # reference src/main.cu:328
