@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s (W x H x spp) of the path-tracer hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one frame: every rank renders the 8-row bands it
+owns (band b belongs to rank b % N) of the SAME W x H x spp frame into a compact HBM buffer,
+then one gather (RCCL over xGMI) brings the bands to rank 0, which de-interleaves them.  The
+total work per step is fixed (strong scaling).  Inputs (scene, camera, previous frame) are
+resident in HBM before the timed region; the frame stays in HBM.
+
+Default workload = BASELINE.json configs[3], the configuration the north-star target is quoted
+on and the largest single-GPU one: low_poly_monkey + emissive sphere light + ground sphere,
+1920x1080, 1024 spp, 8 bounces (configs[1]/[2] are selectable with --scene).
+
+Besides the contract's keys the JSON line carries
+  roofline      the render kernel against the HBM roof (algorithmic bytes: 24 B per pixel per
+                frame + the scene once) — honest reading: this workload is
+                nowhere near HBM-bound, the fraction is tiny by construction;
+  valu          the same kernel against the FP32 vector peak, with algorithmic FLOPs per sample
+                from the counting rule of SURVEY.md §8(d) applied to the oracle's counters;
+  cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/) timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3
+
+
+def flops_per_sample(st):
+    """28*iters + 26*box + 68*tri + 26*sphere_misses + 51*sphere_hits + 105*hits"""
+    n = float(st["samples"])
+    return (28 * st["bounce_iters"] + 26 * st["box_tests"] + 68 * st["tri_tests"] +
+            26 * (st["sphere_tests"] - st["sphere_hits"]) + 51 * st["sphere_hits"] + 105 * st["hits"]) / n
+
+
+def cpu_baseline(rt, objs, sky, W, H, limit, spp_full, budget_s=12.0):
+    """The oracle (det mode, all host threads available to this process) on a bounded sample:
+    the full frame at a reduced spp (per-sample work does not depend on spp)."""
+    from oracle import binding as B
+    B.build()
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # a one-GPU box's CPU share is 16 cores; RT_BENCH_CPU_THREADS overrides
+    threads = int(os.environ.get("RT_BENCH_CPU_THREADS", min(threads, 16)))
+    sc = B.Scene(objs, B.MATH_DET, rt.scenes.models_dir())
+    cam = rt.Camera(W, H).floats()
+    t = time.perf_counter()
+    sc.render(cam, W, H, 1, limit, sky, nthreads=threads)
+    probe = time.perf_counter() - t
+    spp = int(max(1, min(spp_full, budget_s / max(probe, 1e-3))))
+    t = time.perf_counter()
+    _, st = sc.render(cam, W, H, spp, limit, sky, nthreads=threads, with_stats=True)
+    dt = time.perf_counter() - t
+    return {"value": W * H * spp / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": "%dx%d full frame at %d spp of %d, %d bounces, %.1f s" % (W, H, spp, spp_full, limit, dt)}, st
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="monkey", choices=["three_sphere", "cube", "monkey"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--limit", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU; the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    rt = importlib.import_module("ray-tracer_amd")
+    dm = importlib.import_module("ray-tracer_amd.distributed")
+    W, H, spp, limit = args.width, args.height, args.spp, args.limit
+    objs, sky = rt.scenes.CONFIG_SCENES[args.scene]()
+    ctx = rt.Context(local_rank)
+    so = rt.SceneObjects(objs)
+    scene = ctx.commit(so)
+    info = scene.info()
+    cam = rt.Camera(W, H)
+    rd = rt.RenderData(spp, limit, True, sky)
+    band_rows = 8
+    local = torch.zeros((dm.max_owned_rows(H, band_rows, world), W, 3), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world,) + tuple(local.shape), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream().cuda_stream
+    kernel_ms = []
+
+    def step(record):
+        rt.render_device(ctx, scene, cam, rd, 12345, 0, local.data_ptr(), band_first=rank, band_stride=world, compact=True, stream=stream)
+        frame = dm.gather_frame(local, W, H, band_rows, rank, world, dst=0, out=gathered)
+        if record:
+            kernel_ms.append(ctx.last_kernel_ms())   # HIP events on the launch stream; waits for the kernel only
+        return frame
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    frame = None
+    for _ in range(args.steps):
+        frame = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples_per_step = W * H * spp
+    value = samples_per_step * args.steps / elapsed / 1e6
+
+    # per-launch figures for THIS rank's kernel
+    my_rows = min(rt.tile_owned_rows(H, band_rows, rank, world), H)
+    my_pixels = 0
+    for b in dm.owned_bands(H, band_rows, rank, world):
+        my_pixels += (min((b + 1) * band_rows, H) - b * band_rows) * W
+    avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+    flat = so.debug_flatten()
+    scene_bytes = flat["blob"].nbytes + flat["objects"].nbytes
+    algo_bytes = 24.0 * my_pixels + scene_bytes
+    achieved_gbs = algo_bytes / avg_kernel_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        key = "%s_%dx%d_s%d_l%d_n%d" % (args.scene, W, H, spp, limit, world)
+        traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+    roofline = {"bound": "hbm", "kernel": "rt_render_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": avg_kernel_s * 1e3,
+                "note": "24 B/pixel/frame + scene once; the path is VALU/latency-bound, see 'valu'"}
+
+    out = {"metric": "Msamples/sec (WxHxspp) at %dx%d, %d bounces" % (W, H, limit), "value": value, "unit": "Msamples/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%s scene, %dx%d, %d spp, %d bounces, antialias on, time_ms 12345 (BASELINE configs[%d])"
+                      % (args.scene, W, H, spp, limit, {"three_sphere": 1, "cube": 2, "monkey": 3}[args.scene]),
+                      "parallelism": "image bands of 8 rows interleaved over %d GPU(s) + gather to rank 0" % world,
+                      "threads_per_block": info["threads_per_block"], "lds_bytes": info["lds_bytes"]},
+           "roofline": roofline}
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            cb, st = cpu_baseline(rt, objs, sky, W, H, limit, spp)
+            out["cpu_baseline"] = cb
+            fps = flops_per_sample(st)
+            tflops = fps * (my_pixels * spp) / avg_kernel_s / 1e12
+            out["valu"] = {"achieved": tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VECTOR_PEAK_TFLOPS,
+                           "algorithmic_flops_per_sample": fps,
+                           "per_sample": {k: v / float(st["samples"]) for k, v in st.items() if k != "samples"}}
+            out["gpu_over_cpu"] = value / cb["value"]
+        if frame is not None:
+            out["frame_mean"] = float(frame.mean().item())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

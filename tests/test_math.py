@@ -1,0 +1,56 @@
+"""rt_math.h: the deterministic log / sin / cos / tan shared by the HIP kernel and the oracle's
+det mode.  CPU-side checks (through the oracle's orc_math_* hooks, which call rt_math.h when
+mode == DET): accuracy against float64 numpy, special values, and exact known-answer bits so a
+compiler that evaluates the header differently is caught."""
+import os
+
+import numpy as np
+
+from conftest import GOLDEN
+
+
+def _ulps(got, ref64):
+    ref32 = ref64.astype(np.float32)
+    ulp = np.abs(np.nextafter(ref32, np.float32(np.inf)).astype(np.float64) - ref32.astype(np.float64))
+    return np.abs(got.astype(np.float64) - ref64) / ulp
+
+
+def test_logf_accuracy_on_rng_range(orc):
+    L = orc.lib()
+    rng = np.random.default_rng(1)
+    u = (rng.integers(1, 2**32, 20000, dtype=np.uint64).astype(np.float64) / 4294967295.0).astype(np.float32)
+    got = np.array([L.orc_math_logf(float(x), orc.MATH_DET) for x in u], np.float32)
+    mask = u < 1.0                    # log(1) = 0 exactly; ulps of 0 are meaningless
+    assert _ulps(got[mask], np.log(u[mask].astype(np.float64))).max() <= 1.0
+
+
+def test_log_special_values(orc):
+    L = orc.lib()
+    f = lambda x: L.orc_math_logf(x, orc.MATH_DET)
+    assert f(0.0) == -np.inf and f(1.0) == 0.0 and np.isnan(f(-1.0)) and f(np.inf) == np.inf
+    assert abs(f(1e-40) - np.log(1e-40)) < 1e-4       # subnormal input
+    assert np.isnan(f(float("nan")))
+
+
+def test_trig_accuracy(orc):
+    L = orc.lib()
+    xs = np.linspace(0, 6.2832, 20001).astype(np.float32)
+    c = np.array([L.orc_math_cosf(float(x), orc.MATH_DET) for x in xs], np.float32)
+    s = np.array([L.orc_math_sinf(float(x), orc.MATH_DET) for x in xs], np.float32)
+    # absolute error in units of 2^-24 (one ulp at 1.0)
+    assert (np.abs(c.astype(np.float64) - np.cos(xs.astype(np.float64))) / 2.0**-24).max() <= 1.5
+    assert (np.abs(s.astype(np.float64) - np.sin(xs.astype(np.float64))) / 2.0**-24).max() <= 1.5
+    big = np.array([-4000.0, 3217.0, 1e6, 1e9], np.float32)
+    for x in big:
+        assert abs(L.orc_math_cosf(float(x), orc.MATH_DET) - np.cos(np.float64(x))) < 1e-6
+        assert abs(L.orc_math_sinf(float(x), orc.MATH_DET) - np.sin(np.float64(x))) < 1e-6
+    assert np.isnan(L.orc_math_cosf(float("inf"), orc.MATH_DET))
+
+
+def test_math_known_answer_bits(orc):
+    kat = np.load(os.path.join(GOLDEN, "math_kat.npz"))
+    L = orc.lib()
+    for fname, xs in (("logf", kat["xs_log"]), ("cosf", kat["xs_trig"]), ("sinf", kat["xs_trig"]), ("tanf", kat["xs_trig"])):
+        f = getattr(L, "orc_math_" + fname)
+        got = np.array([f(float(x), orc.MATH_DET) for x in xs], np.float32).view(np.uint32)
+        assert np.array_equal(got, kat[fname]), fname
