@@ -43,7 +43,8 @@ enum { RT_OBJ_SPHERE = 0, RT_OBJ_TRIANGLE = 1, RT_OBJ_QUAD = 2, RT_OBJ_ONE_WAY_Q
 #define RT_DEV_MAT_EMISSIVE 1
 #define RT_DEV_MAT_REFRACTIVE 2
 
-typedef struct { float x, y, z, w; } rt_f4;
+/* 16-byte aligned so LDS / global accesses become single b128 instructions */
+typedef struct __attribute__((aligned(16))) { float x, y, z, w; } rt_f4;
 
 /* q0 = (lmin.x lmin.y lmin.z lmax.x) q1 = (lmax.y lmax.z rmin.x rmin.y) q2 = (rmin.z rmax.x rmax.y rmax.z)
  * q3 = (lref, rref, 0, 0) as raw bits */

@@ -33,8 +33,13 @@
 
 #include "rt_device_scene.h"
 #include "rt_math.h"
+#include "rt_rng.h"
 
 #define RT_WAVE 64
+
+/* 16-byte vector for LDS / global accesses: a single ds_read_b128 / global_load_dwordx4 each
+ * (a struct of four floats gets split into narrower loads by the optimiser) */
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct V3 { float x, y, z; };
 
@@ -57,29 +62,20 @@ __device__ __forceinline__ V3 normalised(V3 a)
 }
 __device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
 
-/* src/utils.cu:220-231 — PCG hash of a 32-bit LCG; the uint is divided by 4294967295.0 in
- * binary64 and narrowed to float. */
-__device__ __forceinline__ float pcg_u01(uint32_t &state)
-{
-    uint32_t ns = state * 747796405u + 2891336453u;
-    state = ns;
-    uint32_t r = ((ns >> ((ns >> 28) + 4u)) ^ ns) * 277803737u;
-    r = (r >> 22) ^ r;
-    return (float)((double)r / 4294967295.0);
-}
-
-/* src/utils.cu:234-239 — Box-Muller cosine branch, theta drawn first */
+/* src/utils.cu:234-239 — Box-Muller cosine branch, theta drawn first.  rt_rng.h produces the
+ * reference's (float)(r / 4294967295.0) and the binary64 products derived from it without the
+ * binary64 divide, bit for bit (tests/test_rng_exhaustive.py covers all 2^32 inputs). */
 __device__ __forceinline__ float normal_num(uint32_t &state)
 {
-    float theta = (float)(6.28318 * (double)pcg_u01(state));      /* 2 * 3.14159 * u in binary64 */
-    float rho = sqrtf(-2.0f * rt_logf(pcg_u01(state)));
+    float theta = rt_theta(rt_pcg_next(&state));
+    float rho = sqrtf(-2.0f * rt_logf(rt_u01(rt_pcg_next(&state))));
     return rho * rt_cosf(theta);
 }
 
 struct Lds {
-    const rt_f4 *nodes;
-    const rt_f4 *tris;
-    const rt_f4 *objs;
+    const v4f *nodes;
+    const v4f *tris;
+    const v4f *objs;
     float *stack_d;      /* [RT_STACK_ENTRIES][NT] entry distance */
     uint32_t *stack_r;   /* [RT_STACK_ENTRIES][NT] node reference */
 };
@@ -101,9 +97,9 @@ __device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float 
 }
 
 /* Triangle::hit src/objects.cu:135-163 (Moller-Trumbore, two-sided, no early out) */
-__device__ __forceinline__ bool tri_test(const rt_f4 *tris, int idx, V3 o, V3 d, float &t_out, float &u_out, float &v_out)
+__device__ __forceinline__ bool tri_test(const v4f *tris, int idx, V3 o, V3 d, float &t_out, float &u_out, float &v_out)
 {
-    rt_f4 q0 = tris[3 * idx], q1 = tris[3 * idx + 1], q2 = tris[3 * idx + 2];
+    v4f q0 = tris[3 * idx], q1 = tris[3 * idx + 1], q2 = tris[3 * idx + 2];
     V3 p0 = v3(q0.x, q0.y, q0.z), s1 = v3(q0.w, q1.x, q1.y), s2 = v3(q1.z, q1.w, q2.x);
     V3 p_vec = cross(d, s2);
     float det = dot(s1, p_vec);
@@ -119,7 +115,7 @@ __device__ __forceinline__ bool tri_test(const rt_f4 *tris, int idx, V3 o, V3 d,
 }
 
 /* Quad::hit src/objects.cu:223-236 — t1 if it hits, whatever t2's distance; else t2 */
-__device__ __forceinline__ bool quad_test(const rt_f4 *tris, int first, V3 o, V3 d, float &t_out, int &prim_out)
+__device__ __forceinline__ bool quad_test(const v4f *tris, int first, V3 o, V3 d, float &t_out, int &prim_out)
 {
     float t1, t2, u, v;
     bool h1 = tri_test(tris, first, o, d, t1, u, v);
@@ -154,8 +150,8 @@ __device__ __forceinline__ bool mesh_test(const Lds &L, const rt_object &ob, V3 
                     if (h && t < best) { best = t; best_prim = start + k; }
                 }
             } else {
-                const rt_f4 *n = L.nodes + 4 * (int)cur;
-                rt_f4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+                const v4f *n = L.nodes + 4 * (int)cur;
+                v4f q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
                 float ld, rdist;
                 bool lh = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, ld);
                 bool rh2 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, rdist);
@@ -196,12 +192,12 @@ __device__ __forceinline__ bool mesh_test(const Lds &L, const rt_object &ob, V3 
 template <int NT, bool HAS_MESH>
 __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
 {
-    extern __shared__ rt_f4 lds_raw[];
+    extern __shared__ v4f lds_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & (RT_WAVE - 1);
 
     /* stage the scene into LDS: coalesced 16-byte loads, one pass per workgroup */
-    for (int i = tid; i < a.blob_f4; i += NT) lds_raw[i] = a.blob[i];
+    for (int i = tid; i < a.blob_f4; i += NT) lds_raw[i] = ((const v4f *)a.blob)[i];
     Lds L;
     L.nodes = lds_raw + a.off_nodes;
     L.tris = lds_raw + a.off_tris;
@@ -254,9 +250,9 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
             /* Ray::apply_antialias src/ray.cu:130-142 (binary64 offset arithmetic) */
             if (a.antialias) {
                 V3 off;
-                off.x = (float)(((double)pcg_u01(rng) - 0.5) * 2.0 * (double)0.001f);
-                off.y = (float)(((double)pcg_u01(rng) - 0.5) * 2.0 * (double)0.001f);
-                off.z = (float)(((double)pcg_u01(rng) - 0.5) * 2.0 * (double)0.001f);
+                off.x = rt_jitter(rt_pcg_next(&rng));
+                off.y = rt_jitter(rt_pcg_next(&rng));
+                off.z = rt_jitter(rt_pcg_next(&rng));
                 d = normalised(d + off);
             }
 
@@ -321,7 +317,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                 fin = fin + sky * thr;
                 end_sample = true;
             } else {
-                const rt_f4 ma = L.objs[3 * best_obj], mb = L.objs[3 * best_obj + 1];
+                const v4f ma = L.objs[3 * best_obj], mb = L.objs[3 * best_obj + 1];
                 const uint32_t packed = __float_as_uint(mb.w);
                 const int mtype = (int)(packed & 3u);
                 /* hit point and normal: Ray::get_pos src/ray.cu:63-65; Sphere :66; Triangle :158 */
@@ -329,10 +325,10 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                 V3 N;
                 float tex_u = 0.f, tex_v = 0.f;
                 if (packed & 32u) {
-                    const rt_f4 sc = L.objs[3 * best_obj + 2];
+                    const v4f sc = L.objs[3 * best_obj + 2];
                     N = normalised(P - v3(sc.x, sc.y, sc.z));
                 } else {
-                    const rt_f4 q2 = L.tris[3 * best_prim + 2];
+                    const v4f q2 = L.tris[3 * best_prim + 2];
                     V3 n = v3(q2.y, q2.z, q2.w);
                     N = (dot(n, d) > 0.0f) ? neg(n) : n;
                     if (packed & 16u) {

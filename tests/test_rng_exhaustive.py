@@ -1,0 +1,33 @@
+"""ray-tracer_amd/csrc/rt_rng.h replaces the reference's per-draw binary64 divide
+(src/utils.cu:228) with integer rounding + one binary64 multiply.  That is only admissible if
+it is the same function, so it is compared with the reference's expressions for EVERY 32-bit
+hash output (2^32 cases, ~7 s on 8 threads), not sampled."""
+import os
+import subprocess
+
+from conftest import ROOT
+
+
+def test_rng_forms_match_the_reference_expressions_for_all_inputs(tmp_path):
+    exe = str(tmp_path / "rng_exhaustive")
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-pthread", os.path.join(ROOT, "tests", "rng_exhaustive.c"), "-o", exe])
+    threads = min(os.cpu_count() or 1, 16)
+    stride = os.environ.get("RT_RNG_STRIDE", "1")
+    out = subprocess.run([exe, str(threads), stride], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout
+    assert out.stdout.strip() == "mismatches u01=0 jitter=0 theta=0"
+
+
+def test_oracle_stream_equals_rt_rng(orc):
+    """the oracle draws with the literal divide; a short stream cross-check through its hook"""
+    import ctypes as C
+    import numpy as np
+    vals, _ = orc.pcg_stream(987654321, 64)
+    st = C.c_uint32(987654321)
+    # same stream again, compared with the known hash formula in pure Python
+    state = 987654321
+    for v in vals:
+        state = (state * 747796405 + 2891336453) % 2**32
+        r = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) % 2**32
+        r = (r >> 22) ^ r
+        assert np.float32(v) == np.float32(np.float64(r) / np.float64(4294967295.0))
