@@ -136,7 +136,7 @@ rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_scene **out
 void rt_scene_destroy(rt_scene *s);
 /* introspection for tests: bytes staged in LDS per workgroup, node / triangle counts */
 typedef struct rt_scene_info {
-    int32_t num_objects, num_triangles, num_nodes, lds_bytes, scene_in_lds, threads_per_block;
+    int32_t num_objects, num_triangles, num_nodes, lds_bytes, scene_in_lds, threads_per_block, stack_entries;
 } rt_scene_info;
 rt_status rt_scene_get_info(const rt_scene *s, rt_scene_info *out);
 
@@ -182,11 +182,13 @@ rt_status rt_to_rgba8_device(rt_ctx *ctx, const float *d_rgb, int32_t width, int
  * ray-tracer_amd/csrc/rt_device_scene.h); objects is the scalar-loaded object table. */
 typedef struct rt_flat_view {
     const float *blob; int32_t blob_f4;
-    int32_t off_nodes, off_tris, off_objlds;
+    int32_t off_nodes, off_tris, off_objlds, off_meshes, num_meshes, stack_entries;
     const void *objects; int32_t num_objects, object_stride;
     const float *tri_uv; int32_t num_triangles, num_nodes, has_mesh;
 } rt_flat_view;
 rt_status rt_debug_flatten(rt_scene_builder *b, rt_flat_view *out);
+/* section counters of a development build compiled with -DRT_STATS (all zero otherwise) */
+rt_status rt_debug_read_stats(rt_ctx *ctx, unsigned long long *out24);
 
 const char *rt_version(void);
 

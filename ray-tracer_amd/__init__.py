@@ -48,12 +48,13 @@ class rt_tile_spec(C.Structure):
 
 
 class rt_scene_info(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("num_objects", "num_triangles", "num_nodes", "lds_bytes", "scene_in_lds", "threads_per_block")]
+    _fields_ = [(n, C.c_int32) for n in ("num_objects", "num_triangles", "num_nodes", "lds_bytes", "scene_in_lds", "threads_per_block", "stack_entries")]
 
 
 class rt_flat_view(C.Structure):
     _fields_ = [("blob", C.POINTER(C.c_float)), ("blob_f4", C.c_int32), ("off_nodes", C.c_int32),
-                ("off_tris", C.c_int32), ("off_objlds", C.c_int32), ("objects", C.c_void_p),
+                ("off_tris", C.c_int32), ("off_objlds", C.c_int32), ("off_meshes", C.c_int32), ("num_meshes", C.c_int32),
+                ("stack_entries", C.c_int32), ("objects", C.c_void_p),
                 ("num_objects", C.c_int32), ("object_stride", C.c_int32), ("tri_uv", C.POINTER(C.c_float)),
                 ("num_triangles", C.c_int32), ("num_nodes", C.c_int32), ("has_mesh", C.c_int32)]
 
@@ -69,7 +70,7 @@ ABI_SYMBOLS = [
     "rt_obj_num_triangles", "rt_obj_get_triangles", "rt_camera_default", "rt_camera_make",
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_commit", "rt_scene_destroy",
     "rt_scene_get_info", "rt_render", "rt_render_device", "rt_tile_owned_rows", "rt_last_kernel_ms",
-    "rt_to_rgba8_device", "rt_debug_flatten", "rt_version",
+    "rt_to_rgba8_device", "rt_debug_flatten", "rt_debug_read_stats", "rt_version",
 ]
 
 _lib = None
@@ -81,7 +82,7 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.build()
+    path = os.environ.get("RT_AMD_LIB") or _build.build()      # RT_AMD_LIB: development builds (tools/)
     # PyTorch-ROCm bundles its own libamdhip64.so.7.  Two HIP runtimes in one process cannot
     # both own the GPU, so when torch is installed it is imported first and this library then
     # binds (by SONAME) to the runtime torch already loaded; device pointers and streams are
@@ -152,6 +153,7 @@ def lib():
     L.rt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.rt_to_rgba8_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
     L.rt_debug_flatten.argtypes = [vp, C.POINTER(rt_flat_view)]
+    L.rt_debug_read_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rt_version.restype = C.c_char_p
     _lib = L
     return L
@@ -291,9 +293,12 @@ class ObjFileMesh:
         return out
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().rt_obj_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().rt_obj_destroy(self._h)
+                self._h = None
+        except Exception:      # interpreter shutdown: module globals may already be gone
+            pass
 
 
 class SceneObjects:
@@ -386,13 +391,17 @@ class SceneObjects:
         objs = np.frombuffer(raw, dtype=np.dtype([("type", "<i4"), ("prim_start", "<i4"), ("need_uv", "<i4"), ("root_ref", "<u4"), ("v", "<f4", (8,))]))
         uv = np.ctypeslib.as_array(v.tri_uv, shape=(v.num_triangles, 6)).copy() if v.tri_uv else None
         return {"blob": blob, "off_nodes": v.off_nodes, "off_tris": v.off_tris, "off_objlds": v.off_objlds,
+                "off_meshes": v.off_meshes, "num_meshes": v.num_meshes, "stack_entries": v.stack_entries,
                 "objects": objs, "tri_uv": uv, "num_triangles": v.num_triangles, "num_nodes": v.num_nodes,
                 "has_mesh": bool(v.has_mesh)}
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().rt_scene_builder_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().rt_scene_builder_destroy(self._h)
+                self._h = None
+        except Exception:      # interpreter shutdown: module globals may already be gone
+            pass
 
 
 class Camera:
@@ -475,9 +484,12 @@ class Context:
         return ms.value
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().rt_ctx_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().rt_ctx_destroy(self._h)
+                self._h = None
+        except Exception:      # interpreter shutdown: module globals may already be gone
+            pass
 
 
 class Scene:
@@ -496,9 +508,12 @@ class Scene:
         return {n: getattr(i, n) for n, _ in i._fields_}
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().rt_scene_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().rt_scene_destroy(self._h)
+                self._h = None
+        except Exception:      # interpreter shutdown: module globals may already be gone
+            pass
 
 
 def render(ctx, scene, camera, render_data, data, current_time_ms):

@@ -32,6 +32,13 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
 
 
+def build_variant(name, extra_flags):
+    """development builds (e.g. -DRT_STATS) next to the product library; never loaded by default"""
+    out = os.path.join(HERE, "libraytracer_amd_%s.so" % name)
+    subprocess.check_call([hipcc()] + FLAGS + list(extra_flags) + SOURCES + ["-o", out])
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -31,6 +32,7 @@ struct rt_ctx {
     /* persistent frame buffers for the host-buffer entry point */
     float *d_prev = nullptr, *d_out = nullptr;
     size_t frame_bytes = 0;
+    int work_threshold = 4;      /* lanes; RT_AMD_WORK_THRESHOLD overrides (tuning: tools/ab_threshold.py) */
 };
 
 struct rt_scene {
@@ -83,7 +85,8 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return RT_ERR_NO_DEVICE; }
     ctx->num_cus = prop.multiProcessorCount;
-    if (hipMalloc((void **)&ctx->tile_counter, 256) != hipSuccess ||
+    if (const char *e = getenv("RT_AMD_WORK_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->work_threshold = v; }
+    if (hipMalloc((void **)&ctx->tile_counter, 512) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
         rt_ctx_destroy(ctx);
         return RT_ERR_HIP;
@@ -118,7 +121,7 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
 
     /* workgroup size: the largest one whose LDS (scene + per-lane traversal stacks) fits */
     const size_t blob_bytes = s->flat.blob.size() * sizeof(rt_f4);
-    const size_t per_thread = s->flat.has_mesh ? (size_t)RT_STACK_ENTRIES * 8 : 0;
+    const size_t per_thread = s->flat.has_mesh ? (size_t)s->flat.stack_entries * 8 : 0;
     const int candidates[4] = {1024, 768, 512, 256};
     s->threads = 0;
     if (!s->flat.has_mesh) {
@@ -170,6 +173,7 @@ extern "C" rt_status rt_scene_get_info(const rt_scene *s, rt_scene_info *out)
     out->lds_bytes = (int32_t)s->lds_bytes;
     out->scene_in_lds = 1;
     out->threads_per_block = s->threads;
+    out->stack_entries = s->flat.stack_entries;
     return RT_OK;
 }
 
@@ -224,10 +228,15 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     a.off_nodes = scene->flat.off_nodes;
     a.off_tris = scene->flat.off_tris;
     a.off_objlds = scene->flat.off_objlds;
+    a.off_meshes = scene->flat.off_meshes;
+    a.num_meshes = scene->flat.num_meshes;
+    a.stack_entries = scene->flat.stack_entries;
+    a.work_threshold = ctx->work_threshold;
     a.tri_uv = scene->d_tri_uv;
     a.prev = d_prev;
     a.out = d_out;
     a.tile_counter = ctx->tile_counter;
+    a.stats = (unsigned long long *)(ctx->tile_counter + 16);   /* 24 x u64 after the counter; used by -DRT_STATS builds only */
 
     RT_HIP(ctx, hipEventRecord(ctx->ev_start, stream), "recording start event");
     ctx->have_timing = false;
@@ -242,11 +251,20 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
         int blocks = ctx->num_cus * blocks_per_cu;
         int needed = (a.num_tiles + waves_per_block - 1) / waves_per_block;
         if (blocks > needed) blocks = needed;
-        RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 4, stream), "clearing tile counter");
+        RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 256, stream), "clearing tile counter");
         RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream), "recording stop event");
     ctx->have_timing = true;
+    return RT_OK;
+}
+
+/* development hook: copies the 24 section counters of a -DRT_STATS build (zeros otherwise) */
+extern "C" rt_status rt_debug_read_stats(rt_ctx *ctx, unsigned long long *out24)
+{
+    if (!ctx || !out24) return RT_ERR_INVALID;
+    RT_HIP(ctx, hipDeviceSynchronize(), "waiting for render kernel");
+    RT_HIP(ctx, hipMemcpy(out24, ctx->tile_counter + 16, 24 * 8, hipMemcpyDeviceToHost), "reading stats");
     return RT_OK;
 }
 

@@ -9,15 +9,19 @@
  *     nodes   64 B  both children's boxes + child references (one LDS round trip per step)
  *     tris    48 B  p0, side1, side2, unit normal            (reference src/objects.cu:175-186)
  *     objlds  48 B  per top-level object: what shading needs for a per-lane object index
+ *     meshes  32 B  per mesh object: root box, root reference, object index
  *   global memory, read with wave-uniform (scalar) loads while looping over the object list:
  *     objects 48 B  type, primitive range / BVH root, sphere or root-box constants
  *   global memory, read once per textured hit:
  *     tri_uv  24 B  per-triangle texture coordinates (only when a material needs UVs)
  *
  * The BVH is the reference's tree (fixed depth 10, same split order, same leaf order), with
- * every node's box stored in its parent.  Empty subtrees collapse into an "empty leaf"
- * reference whose stored box is the reference's (0,0,0)-(0,0,0) box, so the strict slab test
- * treats them exactly as the reference does without a special case.
+ * every node's box stored in its parent.  Nodes with an empty child (the reference's split
+ * sends everything left once a node holds <= 2 triangles) are not stored: the edge into such
+ * a chain points at its end and carries RT_REF_CHAIN, which preserves the one observable
+ * effect of the chain (a strict distance test).  Empty subtrees are never entered by a ray
+ * whose direction is not NaN (their (0,0,0)-(0,0,0) box fails the strict slab test), and a NaN
+ * direction hits nothing, so the kernel answers NaN rays without traversing.
  */
 #ifndef RT_DEVICE_SCENE_H
 #define RT_DEVICE_SCENE_H
@@ -29,11 +33,18 @@
 #define RT_INF_F 1073741824.0f       /* reference `1 << 31 - 1` == 1 << 30, src/objects.cu:6 */
 #define RT_EPS_F 0.000001f           /* FLOAT_PRECISION_ERROR src/objects.cu:7 */
 
-/* child / root references */
+/* child / root references: bit 31 leaf, bit 30 chain, leaves: bits 29..20 count, 19..0 first
+ * triangle; internal nodes: bits 29..0 node index.
+ * CHAIN marks an edge that stands for one or more collapsed single-child nodes.  In the
+ * reference such a node re-tests the same box for its only non-empty child and pushes it only
+ * if dist < best (strict, src/objects.cu:517), so an entry reached through a chain is taken
+ * iff dist < best, where a plain popped entry is taken iff !(dist > best) (:501). */
 #define RT_REF_LEAF 0x80000000u
+#define RT_REF_CHAIN 0x40000000u
 #define RT_REF_COUNT_SHIFT 20
-#define RT_REF_COUNT_MAX 2047u
+#define RT_REF_COUNT_MAX 1023u
 #define RT_REF_START_MASK 0x000fffffu
+#define RT_REF_NODE_MASK 0x3fffffffu
 #define RT_REF_EMPTY_LEAF RT_REF_LEAF          /* leaf with zero triangles */
 
 enum { RT_OBJ_SPHERE = 0, RT_OBJ_TRIANGLE = 1, RT_OBJ_QUAD = 2, RT_OBJ_ONE_WAY_QUAD = 3, RT_OBJ_CUBOID = 4, RT_OBJ_MESH = 5 };   /* src/objects.cu:804-809 */
@@ -90,12 +101,16 @@ typedef struct {
     int32_t num_objects;
     const rt_f4 *blob;             /* LDS-staged part */
     int32_t blob_f4;               /* its size in 16-byte units */
-    int32_t off_nodes, off_tris, off_objlds;   /* section offsets in 16-byte units */
+    int32_t off_nodes, off_tris, off_objlds, off_meshes;   /* section offsets in 16-byte units */
+    int32_t num_meshes;
+    int32_t stack_entries;         /* per-lane traversal stack depth (LDS) */
+    int32_t work_threshold;        /* run traversal steps while at least this many lanes traverse */
     const float *tri_uv;           /* 6 floats per triangle, or NULL */
     /* frame buffers */
     const float *prev;             /* full frame or NULL */
     float *out;
     uint32_t *tile_counter;        /* zeroed before the launch */
+    unsigned long long *stats;     /* development builds only (-DRT_STATS): section counters */
 } rt_kernel_args;
 
 #endif

@@ -91,6 +91,7 @@ struct Box {
 struct ChildRef {
     uint32_t ref;
     Box box;
+    int stack_need = 0;   /* deferred-sibling entries a traversal of this subtree can hold at once */
 };
 
 struct BvhBuilder {
@@ -135,7 +136,7 @@ struct BvhBuilder {
         out.box = bounds(idx, pts);
         if (depth <= 0) {
             if (idx.size() > RT_REF_COUNT_MAX || order.size() + idx.size() > RT_REF_START_MASK) {
-                err = "mesh too dense for the compact BVH encoding (leaf > 2047 triangles or > 1M triangles)";
+                err = "mesh too dense for the compact BVH encoding (leaf > 1023 triangles or > 1M triangles)";
                 out.ref = RT_REF_EMPTY_LEAF;
                 return out;
             }
@@ -156,12 +157,19 @@ struct BvhBuilder {
         for (size_t i = 0; i < keyed.size(); i++) (i <= mid ? left : right).push_back(keyed[i].idx);   /* :645 */
         ChildRef l = build(left, depth - 1, pts);
         ChildRef r = build(right, depth - 1, pts);
+        if (right.empty()) {
+            /* single-child node: same triangle set, hence the same box, as its left child.
+             * Not stored; the edge is marked instead (see RT_REF_CHAIN). */
+            l.ref |= RT_REF_CHAIN;
+            return l;
+        }
         rt_node n;
         n.q[0] = rt_f4{l.box.lo[0], l.box.lo[1], l.box.lo[2], l.box.hi[0]};
         n.q[1] = rt_f4{l.box.hi[1], l.box.hi[2], r.box.lo[0], r.box.lo[1]};
         n.q[2] = rt_f4{r.box.lo[2], r.box.hi[0], r.box.hi[1], r.box.hi[2]};
         n.q[3] = rt_f4{rt_u2f(l.ref), rt_u2f(r.ref), 0.0f, 0.0f};
         out.ref = (uint32_t)nodes.size();
+        out.stack_need = 1 + std::max(l.stack_need, r.stack_need);
         nodes.push_back(n);
         return out;
     }
@@ -178,6 +186,7 @@ rt_status add_mesh_tris(rt_scene_builder *b, const std::vector<HostTri> &tris, c
     ChildRef root = bb.build(idx, RT_BVH_DEPTH, pts);   /* Mesh :786: BVH(..., 10) */
     if (!bb.err.empty()) return fail(b, RT_ERR_UNSUPPORTED, bb.err.c_str());
     o.root_ref = root.ref;
+    o.stack_need = root.stack_need;
     for (int k = 0; k < 3; k++) { o.v[k] = root.box.lo[k]; o.v[3 + k] = root.box.hi[k]; }
     o.nodes = std::move(bb.nodes);
     o.tris.reserve(tris.size());
@@ -594,15 +603,20 @@ std::string rt_flatten(const rt_scene_builder &b, FlatScene &out)
         if (o.mat.need_uv && o.type != RT_OBJ_SPHERE) any_uv = true;
     }
     if (n_tris > RT_REF_START_MASK) return "scene has too many triangles for the compact encoding";
+    size_t n_meshes = 0;
+    for (const HostObject &o : b.objs) n_meshes += o.type == RT_OBJ_MESH;
     out.off_nodes = 0;
     out.off_tris = (int)(n_nodes * 4);
     out.off_objlds = out.off_tris + (int)(n_tris * 3);
-    out.blob.resize((size_t)out.off_objlds + b.objs.size() * 3);
+    out.off_meshes = out.off_objlds + (int)(b.objs.size() * 3);
+    out.num_meshes = (int)n_meshes;
+    out.blob.resize((size_t)out.off_meshes + n_meshes * 2);
+    out.stack_entries = 1;
     out.num_nodes = (int)n_nodes;
     out.num_tris = (int)n_tris;
     if (any_uv) out.tri_uv.resize(n_tris * 6, 0.0f);
 
-    size_t node_base = 0, tri_base = 0;
+    size_t node_base = 0, tri_base = 0, mesh_i = 0;
     for (size_t oi = 0; oi < b.objs.size(); oi++) {
         const HostObject &o = b.objs[oi];
         rt_object ro;
@@ -613,15 +627,24 @@ std::string rt_flatten(const rt_scene_builder &b, FlatScene &out)
         ro.root_ref = o.root_ref;
         std::memcpy(ro.v, o.v, sizeof ro.v);
         auto rebase = [&](uint32_t ref) -> uint32_t {
+            const uint32_t chain = ref & RT_REF_CHAIN;
             if (ref & RT_REF_LEAF) {
                 uint32_t count = (ref >> RT_REF_COUNT_SHIFT) & RT_REF_COUNT_MAX;
                 if (count == 0) return RT_REF_EMPTY_LEAF;
                 uint32_t start = (ref & RT_REF_START_MASK) + (uint32_t)tri_base;
-                return RT_REF_LEAF | (count << RT_REF_COUNT_SHIFT) | start;
+                return RT_REF_LEAF | chain | (count << RT_REF_COUNT_SHIFT) | start;
             }
-            return ref + (uint32_t)node_base;
+            return ((ref & RT_REF_NODE_MASK) + (uint32_t)node_base) | chain;
         };
-        if (o.type == RT_OBJ_MESH) ro.root_ref = rebase(o.root_ref);
+        if (o.type == RT_OBJ_MESH) {
+            ro.root_ref = rebase(o.root_ref);
+            /* mesh table entry: (root box min, max.x) (max.yz, root_ref, object index) */
+            rt_f4 *mt = &out.blob[(size_t)out.off_meshes + mesh_i * 2];
+            mt[0] = rt_f4{o.v[0], o.v[1], o.v[2], o.v[3]};
+            mt[1] = rt_f4{o.v[4], o.v[5], rt_u2f(ro.root_ref), rt_u2f((uint32_t)oi)};
+            mesh_i++;
+            out.stack_entries = std::max(out.stack_entries, o.stack_need);
+        }
         for (size_t k = 0; k < o.nodes.size(); k++) {
             rt_node n = o.nodes[k];
             n.q[3].x = rt_u2f(rebase(rt_f2u(n.q[3].x)));
@@ -667,6 +690,9 @@ extern "C" rt_status rt_debug_flatten(rt_scene_builder *b, rt_flat_view *out)
     out->off_nodes = f.off_nodes;
     out->off_tris = f.off_tris;
     out->off_objlds = f.off_objlds;
+    out->off_meshes = f.off_meshes;
+    out->num_meshes = f.num_meshes;
+    out->stack_entries = f.stack_entries;
     out->objects = f.objects.data();
     out->num_objects = (int32_t)f.objects.size();
     out->object_stride = (int32_t)sizeof(rt_object);

@@ -23,6 +23,7 @@ struct HostObject {
     std::vector<HostTri> tris;           /* top-level shapes: 1 / 2 / 12; meshes: leaf order */
     std::vector<rt_node> nodes;          /* meshes: child refs relative to this object */
     uint32_t root_ref = RT_REF_EMPTY_LEAF;
+    int stack_need = 0;
 };
 
 struct FlatScene;
@@ -42,7 +43,9 @@ struct rt_obj {
 /* flattened scene, ready to upload */
 struct FlatScene {
     std::vector<rt_f4> blob;
-    int off_nodes = 0, off_tris = 0, off_objlds = 0;
+    int off_nodes = 0, off_tris = 0, off_objlds = 0, off_meshes = 0;
+    int num_meshes = 0;
+    int stack_entries = 1;                       /* per-lane traversal stack depth this scene needs */
     std::vector<rt_object> objects;
     std::vector<float> tri_uv;                   /* empty unless some material needs UVs */
     int num_tris = 0, num_nodes = 0;

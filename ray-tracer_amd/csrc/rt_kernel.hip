@@ -10,11 +10,15 @@
  * average (src/raytracer.cu:97-113).  The arithmetic (types, order, the double-precision
  * fragments) is the reference's; the program structure is not:
  *
- *  - one wave = one 8x8 pixel tile; waves pull tiles from a global counter until none are
- *    left, so a workgroup never idles behind its slowest tile;
- *  - the spp loop and the bounce loop are ONE flat loop per lane: a lane whose sample ended
- *    starts its next sample in the next iteration instead of waiting for the longest path of
+ *  - every lane is a small state machine (fetch pixel -> generate bounce -> mesh traversal ->
+ *    shade -> ...).  Lanes take pixels one by one (tile-major ids handed out per wave from a
+ *    global tile counter), so no lane waits for the slowest pixel of a tile; the spp loop and
+ *    the bounce loop are one flat sequence per lane, so no lane waits for the longest path of
  *    the wave (the RNG stream stays per-pixel-sequential, SURVEY.md §7 hard part 3);
+ *  - BVH traversal is decoupled from the bounce loop: lanes that need it park in a wait state
+ *    and the wave runs traversal steps only while enough lanes (a ballot count) are
+ *    traversing; lanes whose ray missed every mesh box, or finished early, go on shading and
+ *    generating instead of idling behind the longest traversal;
  *  - the whole scene (BVH nodes with child boxes inline, 48-byte triangles, per-object
  *    shading record) is staged into LDS once per workgroup; the object list itself is read
  *    with scalar loads because every lane walks it in the same order;
@@ -76,8 +80,9 @@ struct Lds {
     const v4f *nodes;
     const v4f *tris;
     const v4f *objs;
-    float *stack_d;      /* [RT_STACK_ENTRIES][NT] entry distance */
-    uint32_t *stack_r;   /* [RT_STACK_ENTRIES][NT] node reference */
+    const v4f *meshes;
+    float *stack_d;      /* [stack_entries][NT] entry distance of the deferred sibling */
+    uint32_t *stack_r;   /* [stack_entries][NT] its reference */
 };
 
 /* BoundingBox::ray_hits src/objects.cu:404-434.  fminf/fmaxf drop a NaN operand like CUDA's
@@ -125,69 +130,17 @@ __device__ __forceinline__ bool quad_test(const v4f *tris, int first, V3 o, V3 d
     return h1 || h2;
 }
 
-/* BVH::traverse src/objects.cu:487-532 + check_leaf_node :586-600 on the compact tree.
- * Visit order, push order and every comparison are the reference's; only the bookkeeping
- * differs (see the file header). */
-template <int NT>
-__device__ __forceinline__ bool mesh_test(const Lds &L, const rt_object &ob, V3 o, V3 d, V3 inv, int tid,
-                                          float &t_out, int &prim_out)
-{
-    float best = RT_INF_F;
-    int best_prim = -1;
-    float rd;
-    /* the root is pushed unconditionally and tested when popped (:494-501) */
-    bool rh = box_test(ob.v[0], ob.v[1], ob.v[2], ob.v[3], ob.v[4], ob.v[5], o, inv, rd);
-    if (rh && !(rd > best)) {
-        uint32_t cur = ob.root_ref;
-        int sp = 0;
-        for (;;) {
-            if (cur & RT_REF_LEAF) {
-                int start = (int)(cur & RT_REF_START_MASK);
-                int count = (int)((cur >> RT_REF_COUNT_SHIFT) & RT_REF_COUNT_MAX);
-                for (int k = 0; k < count; k++) {
-                    float t, u, v;
-                    bool h = tri_test(L.tris, start + k, o, d, t, u, v);
-                    if (h && t < best) { best = t; best_prim = start + k; }
-                }
-            } else {
-                const v4f *n = L.nodes + 4 * (int)cur;
-                v4f q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-                float ld, rdist;
-                bool lh = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, ld);
-                bool rh2 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, rdist);
-                uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
-                bool l_push = lh && ld < best;
-                bool r_push = rh2 && rdist < best;
-                bool l_first = ld < rdist;
-                /* "first" is pushed first and therefore visited second */
-                uint32_t first_ref = l_first ? lref : rref, second_ref = l_first ? rref : lref;
-                float first_d = l_first ? ld : rdist;
-                bool first_push = l_first ? l_push : r_push, second_push = l_first ? r_push : l_push;
-                if (second_push) {
-                    if (first_push) {
-                        L.stack_d[sp * NT + tid] = first_d;
-                        L.stack_r[sp * NT + tid] = first_ref;
-                        sp++;
-                    }
-                    cur = second_ref;       /* popped immediately: its distance is still < best */
-                    continue;
-                }
-                if (first_push) { cur = first_ref; continue; }
-            }
-            /* pop: skip entries that the best hit has overtaken (:501) */
-            bool found = false;
-            while (sp > 0) {
-                sp--;
-                float dd = L.stack_d[sp * NT + tid];
-                if (!(dd > best)) { cur = L.stack_r[sp * NT + tid]; found = true; break; }
-            }
-            if (!found) break;
-        }
-    }
-    t_out = best;
-    prim_out = best_prim;
-    return best_prim >= 0;
-}
+/* Development instrumentation (-DRT_STATS, tools/stats_run.py): per code section, how many
+ * times a wave executed it and with how many active lanes.  Compiled out of the product. */
+#ifdef RT_STATS
+#define RT_STAT(slot) do { unsigned long long m_ = __ballot(1); if (lane == __builtin_ctzll(m_)) { st_exec[slot] += 1u; st_lanes[slot] += (unsigned)__popcll(m_); } } while (0)
+#else
+#define RT_STAT(slot) do { } while (0)
+#endif
+enum { ST_ITER = 0, ST_SHADE = 1, ST_SHADE_HIT = 2, ST_FETCH = 3, ST_GEN = 4, ST_MESH = 5, ST_MESH_START = 6, ST_WORK_ITER = 7, ST_NODE = 8, ST_LEAF_TRI = 9, ST_POP = 10, ST_DONE_MESH = 11, ST_N = 12 };
+
+/* lane states of the render loop */
+enum { M_FETCH = 0, M_GEN = 1, M_MESH = 2, M_WAIT = 3, M_SHADE = 4, M_DONE = 5 };
 
 template <int NT, bool HAS_MESH>
 __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
@@ -202,8 +155,9 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
     L.nodes = lds_raw + a.off_nodes;
     L.tris = lds_raw + a.off_tris;
     L.objs = lds_raw + a.off_objlds;
+    L.meshes = lds_raw + a.off_meshes;
     L.stack_d = (float *)(lds_raw + a.blob_f4);
-    L.stack_r = (uint32_t *)(L.stack_d + RT_STACK_ENTRIES * NT);
+    L.stack_r = (uint32_t *)(L.stack_d + a.stack_entries * NT);
     __syncthreads();
 
     const V3 cam_pos = v3(a.cam[0], a.cam[1], a.cam[2]);
@@ -213,110 +167,40 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
     const V3 sky = v3(a.sky[0], a.sky[1], a.sky[2]);
     const int W = a.width, H = a.height;
     const int spp = a.rays_per_pixel, limit = a.reflection_limit;
+    const int tiles_per_band = a.tiles_x * (a.band_rows >> 3);
+
+    /* ---- per-lane pixel state (registers) ---- */
+    int mode = M_FETCH;
+    uint32_t rng = 0;
+    V3 colour = v3(0.f, 0.f, 0.f), fin = colour, thr = colour, o = colour, d = colour, inv = colour, primary = colour;
+    int sample = 0, bounce = 0, px = 0, py = 0;
+    float best_t = RT_INF_F;
+    int best_obj = -1, best_prim = -1, next_mesh = 0;
+    /* ---- per-lane traversal state (registers + LDS stack) ---- */
+    bool w_active = false;
+    uint32_t cur = 0;
+    int sp = 0, w_prim = -1, w_obj = -1;
+    float w_best = RT_INF_F;
+    /* ---- wave-uniform pixel chunk: linear pixel ids [chunk_next, chunk_end) of one 8x8 tile ---- */
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false;
+#ifdef RT_STATS
+    unsigned st_exec[ST_N], st_lanes[ST_N];
+    for (int i = 0; i < ST_N; i++) { st_exec[i] = 0; st_lanes[i] = 0; }
+#endif
 
     for (;;) {
-        /* one 8x8 tile per wave, handed out by a global counter */
-        uint32_t tile = 0;
-        if (lane == 0) tile = atomicAdd(a.tile_counter, 1u);
-        tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-        if (tile >= (uint32_t)a.num_tiles) break;
-
-        const int tiles_per_band = a.tiles_x * (a.band_rows >> 3);
-        const int band_local = (int)tile / tiles_per_band;            /* k-th band owned by this launch */
-        const int in_band = (int)tile % tiles_per_band;
-        const int band = a.band_first + band_local * a.band_stride;   /* global band index */
-        const int ty = in_band / a.tiles_x, tx = in_band % a.tiles_x;
-        const int px = tx * 8 + (lane & 7);
-        const int py_in_band = ty * 8 + (lane >> 3);
-        const int py = band * a.band_rows + py_in_band;
-        const bool in_image = px < W && py < H;
-
-        /* src/raytracer.cu:123-127 */
-        const int array_index = (py * W + px) * 3;
-        uint32_t rng = (uint32_t)array_index * 3145739u + a.seed_time;
-
-        /* Ray::set_direction_origin src/ray.cu:147-155, cam_pixel_to_world src/camera.cu:24-29 */
-        V3 plane_point = du * (float)px + dv * (float)py;
-        V3 view_pos = tl + plane_point;
-        const V3 primary = normalised(view_pos - cam_pos);
-
-        V3 colour = v3(0.f, 0.f, 0.f);
-        V3 fin = v3(0.f, 0.f, 0.f), thr = v3(1.f, 1.f, 1.f);
-        V3 o = cam_pos, d = primary;
-        int sample = (in_image && limit > 0) ? 0 : spp;
-        int bounce = 0;
-
-        while (sample < spp) {
-            /* Ray::apply_antialias src/ray.cu:130-142 (binary64 offset arithmetic) */
-            if (a.antialias) {
-                V3 off;
-                off.x = rt_jitter(rt_pcg_next(&rng));
-                off.y = rt_jitter(rt_pcg_next(&rng));
-                off.z = rt_jitter(rt_pcg_next(&rng));
-                d = normalised(d + off);
-            }
-
-            /* get_ray_collision src/raytracer.cu:24-46 */
-            float best_t = RT_INF_F;
-            int best_obj = -1, best_prim = -1;
-            V3 inv = v3(0.f, 0.f, 0.f);
-            if (HAS_MESH) inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   /* src/ray.cu:198-202 */
-
-            for (int i = 0; i < a.num_objects; i++) {
-                const rt_object ob = a.objects[i];
-                bool hit = false;
-                float t = RT_INF_F;
-                int prim = -1;
-                switch (ob.type) {
-                    case RT_OBJ_SPHERE: {   /* Sphere::hit src/objects.cu:40-79: near root, > 1e-6 */
-                        V3 cq = v3(ob.v[0], ob.v[1], ob.v[2]) - o;
-                        float qa = dot(d, d);
-                        float qb = dot(d, cq) * (-2.0f);
-                        float qc = dot(cq, cq) - ob.v[3] * ob.v[3];
-                        float disc = qb * qb - 4.0f * qa * qc;
-                        if (disc >= 0.0f) {
-                            float dist = (-qb - sqrtf(disc)) / (2.0f * qa);
-                            if (dist > RT_EPS_F) { hit = true; t = dist; }
-                        }
-                        break;
-                    }
-                    case RT_OBJ_TRIANGLE: {
-                        float u, v;
-                        hit = tri_test(L.tris, ob.prim_start, o, d, t, u, v);
-                        prim = ob.prim_start;
-                        break;
-                    }
-                    case RT_OBJ_ONE_WAY_QUAD:   /* src/objects.cu:273-280 */
-                        if (dot(d, v3(ob.v[0], ob.v[1], ob.v[2])) < 0.0f) break;
-                        /* fall through */
-                    case RT_OBJ_QUAD:
-                        hit = quad_test(L.tris, ob.prim_start, o, d, t, prim);
-                        break;
-                    case RT_OBJ_CUBOID: {       /* src/objects.cu:305-322: strict <, first face wins ties */
-                        float cb = RT_INF_F;
-                        for (int f = 0; f < 6; f++) {
-                            float ft; int fp;
-                            bool fh = quad_test(L.tris, ob.prim_start + 2 * f, o, d, ft, fp);
-                            if (fh && ft < cb) { cb = ft; prim = fp; hit = true; }
-                        }
-                        t = cb;
-                        break;
-                    }
-                    case RT_OBJ_MESH:
-                        if (HAS_MESH) hit = mesh_test<NT>(L, ob, o, d, inv, tid, t, prim);
-                        break;
-                }
-                /* `<=`: the later object wins ties (:36); the precision_error term is a no-op
-                 * for accepted hits */
-                if (hit && t <= best_t) { best_t = t; best_obj = i; best_prim = prim; }
-            }
-
+        RT_STAT(ST_ITER);
+        /* ================= SHADE: the closest hit of this bounce is known ================== */
+        if (mode == M_SHADE) {
+            RT_STAT(ST_SHADE);
             bool end_sample;
             if (best_obj < 0) {
                 /* src/raytracer.cu:76-80 */
                 fin = fin + sky * thr;
                 end_sample = true;
             } else {
+                RT_STAT(ST_SHADE_HIT);
                 const v4f ma = L.objs[3 * best_obj], mb = L.objs[3 * best_obj + 1];
                 const uint32_t packed = __float_as_uint(mb.w);
                 const int mtype = (int)(packed & 3u);
@@ -375,29 +259,280 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                 bounce++;
                 end_sample = bounce >= limit;
             }
-
+            mode = M_GEN;
             if (end_sample) {
-                /* src/raytracer.cu:102-105: next sample restarts from a copy of the primary ray */
+                /* src/raytracer.cu:102-105: the next sample restarts from a copy of the primary ray */
                 colour = colour + fin;
                 sample++;
                 fin = v3(0.f, 0.f, 0.f); thr = v3(1.f, 1.f, 1.f);
                 o = cam_pos; d = primary; bounce = 0;
+                if (sample >= spp) {
+                    /* src/raytracer.cu:107-112 and :133-135 */
+                    const int array_index = (py * W + px) * 3;
+                    V3 c = colour / (float)spp;
+                    V3 previous = v3(0.f, 0.f, 0.f);
+                    if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
+                    V3 previous_sum = previous * (float)a.frame_num;
+                    V3 res = (c + previous_sum) / (float)(a.frame_num + 1);
+                    int out_row = py;
+                    if (a.compact) {
+                        const int band = py / a.band_rows;
+                        out_row = ((band - a.band_first) / a.band_stride) * a.band_rows + (py - band * a.band_rows);
+                    }
+                    float *dst = a.out + ((size_t)out_row * (size_t)W + (size_t)px) * 3;
+                    dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+                    mode = M_FETCH;
+                }
             }
         }
 
-        if (in_image) {
-            /* src/raytracer.cu:107-112 and :133-135 */
-            if (limit <= 0) colour = v3(0.f, 0.f, 0.f);
-            colour = colour / (float)spp;
-            V3 previous = v3(0.f, 0.f, 0.f);
-            if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
-            V3 previous_sum = previous * (float)a.frame_num;
-            V3 res = (colour + previous_sum) / (float)(a.frame_num + 1);
-            const int out_row = a.compact ? (band_local * a.band_rows + py_in_band) : py;
-            float *dst = a.out + ((size_t)out_row * (size_t)W + (size_t)px) * 3;
-            dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+        /* ================= FETCH: lanes without a pixel take the next ones ==================
+         * Linear pixel ids are tile-major (64 per 8x8 tile), tiles come from a global counter;
+         * a wave asks for one tile at a time and hands its ids out to whichever lanes are free. */
+        {
+            const bool want = mode == M_FETCH;
+            const unsigned long long mask = __ballot(want);
+            if (mask) {
+                const int need = __popcll(mask);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                int taken = 0;
+                int my_id = -1;
+                for (;;) {
+                    const int avail = (int)(chunk_end - chunk_next);
+                    const int take = avail < need - taken ? avail : need - taken;
+                    if (want && rank >= taken && rank < taken + take) my_id = (int)chunk_next + (rank - taken);
+                    chunk_next += (uint32_t)take;
+                    taken += take;
+                    if (taken == need || exhausted) break;
+                    uint32_t t = 0;
+                    if (lane == 0) t = atomicAdd(a.tile_counter, 1u);
+                    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                    if (t >= (uint32_t)a.num_tiles) { exhausted = true; break; }
+                    chunk_next = t * 64u;
+                    chunk_end = t * 64u + 64u;
+                }
+                if (want) {
+                    if (my_id < 0) {
+                        mode = M_DONE;
+                    } else {
+                        const int tile = my_id >> 6, within = my_id & 63;
+                        const int band_local = tile / tiles_per_band;
+                        const int in_band = tile - band_local * tiles_per_band;
+                        const int band = a.band_first + band_local * a.band_stride;
+                        const int ty = in_band / a.tiles_x, tx = in_band - ty * a.tiles_x;
+                        px = tx * 8 + (within & 7);
+                        py = band * a.band_rows + ty * 8 + (within >> 3);
+                        if (px < W && py < H) {
+                            /* src/raytracer.cu:123-127; Ray::set_direction_origin src/ray.cu:147-155,
+                             * cam_pixel_to_world src/camera.cu:24-29 */
+                            const int array_index = (py * W + px) * 3;
+                            rng = (uint32_t)array_index * 3145739u + a.seed_time;
+                            V3 plane_point = du * (float)px + dv * (float)py;
+                            primary = normalised((tl + plane_point) - cam_pos);
+                            colour = v3(0.f, 0.f, 0.f);
+                            fin = v3(0.f, 0.f, 0.f); thr = v3(1.f, 1.f, 1.f);
+                            o = cam_pos; d = primary;
+                            bounce = 0;
+                            /* a zero bounce limit traces nothing: every sample is (0,0,0) */
+                            sample = limit > 0 ? 0 : spp;
+                            if (sample >= spp) {
+                                const float q = 0.0f / (float)spp;               /* NaN for spp == 0, like the reference */
+                                V3 previous = v3(0.f, 0.f, 0.f);
+                                if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
+                                V3 res = (v3(q, q, q) + previous * (float)a.frame_num) / (float)(a.frame_num + 1);
+                                int out_row = py;
+                                if (a.compact) out_row = band_local * a.band_rows + (py - band * a.band_rows);
+                                float *dst = a.out + ((size_t)out_row * (size_t)W + (size_t)px) * 3;
+                                dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+                                /* stays in M_FETCH: takes another pixel next time round */
+                            } else {
+                                mode = M_GEN;
+                            }
+                        }
+                        /* a pixel outside the image (ragged edge tile): stay in M_FETCH */
+                    }
+                }
+            }
         }
+
+        /* ================= GEN: jitter the direction, test the simple objects ============== */
+        if (mode == M_GEN) {
+            RT_STAT(ST_GEN);
+            /* Ray::apply_antialias src/ray.cu:130-142 */
+            if (a.antialias) {
+                V3 off;
+                off.x = rt_jitter(rt_pcg_next(&rng));
+                off.y = rt_jitter(rt_pcg_next(&rng));
+                off.z = rt_jitter(rt_pcg_next(&rng));
+                d = normalised(d + off);
+            }
+            if (HAS_MESH) inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   /* src/ray.cu:198-202 */
+
+            /* get_ray_collision src/raytracer.cu:24-46 over the non-mesh objects, in list order
+             * (`<=`: the later object wins ties, :36; the precision_error term is a no-op for
+             * accepted hits).  Meshes are merged afterwards with the same
+             * rule made explicit: smaller distance, or equal distance and larger list index. */
+            best_t = RT_INF_F; best_obj = -1; best_prim = -1;
+            for (int i = 0; i < a.num_objects; i++) {
+                const rt_object ob = a.objects[i];
+                bool hit = false;
+                float t = RT_INF_F;
+                int prim = -1;
+                switch (ob.type) {
+                    case RT_OBJ_SPHERE: {   /* Sphere::hit src/objects.cu:40-79: near root, > 1e-6 */
+                        V3 cq = v3(ob.v[0], ob.v[1], ob.v[2]) - o;
+                        float qa = dot(d, d);
+                        float qb = dot(d, cq) * (-2.0f);
+                        float qc = dot(cq, cq) - ob.v[3] * ob.v[3];
+                        float disc = qb * qb - 4.0f * qa * qc;
+                        if (disc >= 0.0f) {
+                            float dist = (-qb - sqrtf(disc)) / (2.0f * qa);
+                            if (dist > RT_EPS_F) { hit = true; t = dist; }
+                        }
+                        break;
+                    }
+                    case RT_OBJ_TRIANGLE: {
+                        float u, v;
+                        hit = tri_test(L.tris, ob.prim_start, o, d, t, u, v);
+                        prim = ob.prim_start;
+                        break;
+                    }
+                    case RT_OBJ_ONE_WAY_QUAD:   /* src/objects.cu:273-280 */
+                        if (dot(d, v3(ob.v[0], ob.v[1], ob.v[2])) < 0.0f) break;
+                        /* fall through */
+                    case RT_OBJ_QUAD:
+                        hit = quad_test(L.tris, ob.prim_start, o, d, t, prim);
+                        break;
+                    case RT_OBJ_CUBOID: {       /* src/objects.cu:305-322: strict <, first face wins ties */
+                        float cb = RT_INF_F;
+                        for (int f = 0; f < 6; f++) {
+                            float ft; int fp;
+                            bool fh = quad_test(L.tris, ob.prim_start + 2 * f, o, d, ft, fp);
+                            if (fh && ft < cb) { cb = ft; prim = fp; hit = true; }
+                        }
+                        t = cb;
+                        break;
+                    }
+                    default: break;             /* RT_OBJ_MESH: below */
+                }
+                if (hit && t <= best_t) { best_t = t; best_obj = i; best_prim = prim; }
+            }
+            next_mesh = 0;
+            mode = (HAS_MESH && a.num_meshes > 0) ? M_MESH : M_SHADE;
+        }
+
+        if (HAS_MESH) {
+            /* ================= MESH: find the next mesh whose root box the ray enters ======= */
+            while (mode == M_MESH) {
+                RT_STAT(ST_MESH);
+                if (next_mesh >= a.num_meshes) { mode = M_SHADE; break; }
+                const v4f m0 = L.meshes[2 * next_mesh], m1 = L.meshes[2 * next_mesh + 1];
+                next_mesh++;
+                /* a NaN direction (Box-Muller on a zero draw) fails every
+                 * triangle test: the mesh cannot be hit, no need to walk it */
+                if (d.x != d.x || d.y != d.y || d.z != d.z) continue;
+                /* the root is pushed unconditionally and tested when popped (src/objects.cu:494-501) */
+                const uint32_t root_ref = __float_as_uint(m1.z);
+                float rd;
+                const bool rh = box_test(m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, o, inv, rd);
+                if (!rh || rd > RT_INF_F || ((root_ref & RT_REF_CHAIN) && !(rd < RT_INF_F))) continue;
+                cur = root_ref; sp = 0; w_best = RT_INF_F; w_prim = -1; w_obj = (int)__float_as_uint(m1.w);
+                w_active = true;
+                mode = M_WAIT;
+                RT_STAT(ST_MESH_START);
+            }
+
+            /* ================= WORK: BVH traversal steps (src/objects.cu:487-532, :586-600) ====
+             * Runs while enough lanes are traversing; lanes whose ray is finished go back to
+             * shading as soon as the traversing group is small.  Visit order, push order and
+             * every comparison are the reference's. */
+            for (;;) {
+                const int n_active = __popcll(__ballot(w_active));
+                if (n_active == 0) break;
+                const bool other_ready = __ballot(mode != M_WAIT && mode != M_DONE) != 0ull;
+                if (n_active < a.work_threshold && other_ready) break;
+                if (w_active) {
+                    RT_STAT(ST_WORK_ITER);
+                    /* one macro step: descend to a leaf (or run out of children), test the
+                     * leaf's triangles, pop the next deferred sibling.  (A variant that
+                     * schedules node steps and single-triangle steps by lane majority issued
+                     * ~30 % fewer wave instructions but ran slower: the extra ballots and
+                     * branches lengthen each wave's serial instruction stream, and at the 4
+                     * waves/SIMD an LDS-resident scene allows that latency is not hidden.) */
+                    bool at_leaf = (cur & RT_REF_LEAF) != 0u;
+                    if (!at_leaf) {
+                        for (;;) {
+                            RT_STAT(ST_NODE);
+                            const v4f *n = L.nodes + 4 * (int)(cur & RT_REF_NODE_MASK);
+                            v4f q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+                            float ld, rdist;
+                            bool lh = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, ld);
+                            bool rh2 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, rdist);
+                            uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+                            bool l_push = lh && ld < w_best;
+                            bool r_push = rh2 && rdist < w_best;
+                            bool l_first = ld < rdist;
+                            /* "first" is pushed first and therefore visited second */
+                            uint32_t first_ref = l_first ? lref : rref, second_ref = l_first ? rref : lref;
+                            float first_d = l_first ? ld : rdist;
+                            bool first_push = l_first ? l_push : r_push, second_push = l_first ? r_push : l_push;
+                            if (second_push) {
+                                if (first_push) {
+                                    L.stack_d[sp * NT + tid] = first_d;
+                                    L.stack_r[sp * NT + tid] = first_ref;
+                                    sp++;
+                                }
+                                cur = second_ref;       /* popped immediately: its distance is still < best */
+                            } else if (first_push) {
+                                cur = first_ref;
+                            } else {
+                                break;                  /* nothing entered: pop */
+                            }
+                            if (cur & RT_REF_LEAF) { at_leaf = true; break; }
+                        }
+                    }
+                    if (at_leaf) {
+                        /* leaf: strict <, first triangle wins ties (:596) */
+                        const int start = (int)(cur & RT_REF_START_MASK);
+                        const int count = (int)((cur >> RT_REF_COUNT_SHIFT) & RT_REF_COUNT_MAX);
+                        for (int k = 0; k < count; k++) {
+                            RT_STAT(ST_LEAF_TRI);
+                            float t, u, v;
+                            bool h = tri_test(L.tris, start + k, o, d, t, u, v);
+                            if (h && t < w_best) { w_best = t; w_prim = start + k; }
+                        }
+                    }
+                    /* pop: an entry is taken iff !(dist > best) (:501); through a collapsed chain
+                     * iff dist < best (:517) */
+                    bool found = false;
+                    while (sp > 0) {
+                        RT_STAT(ST_POP);
+                        sp--;
+                        const float dd = L.stack_d[sp * NT + tid];
+                        const uint32_t rr = L.stack_r[sp * NT + tid];
+                        const bool take = (rr & RT_REF_CHAIN) ? (dd < w_best) : !(dd > w_best);
+                        if (take) { cur = rr; found = true; break; }
+                    }
+                    if (!found) {
+                        RT_STAT(ST_DONE_MESH);
+                        /* this mesh is done: merge (smaller distance, or equal and later in the list) */
+                        if (w_prim >= 0 && (w_best < best_t || (w_best == best_t && w_obj > best_obj))) {
+                            best_t = w_best; best_obj = w_obj; best_prim = w_prim;
+                        }
+                        w_active = false;
+                        mode = next_mesh >= a.num_meshes ? M_SHADE : M_MESH;
+                    }
+                }
+            }
+        }
+
+        if (__ballot(mode != M_DONE) == 0ull) break;
     }
+#ifdef RT_STATS
+    for (int i = 0; i < ST_N; i++) {
+        if (st_exec[i]) { atomicAdd(&a.stats[2 * i], (unsigned long long)st_exec[i]); atomicAdd(&a.stats[2 * i + 1], (unsigned long long)st_lanes[i]); }
+    }
+#endif
 }
 
 /* float -> RGBA8 of src/main.cu:343-371 */

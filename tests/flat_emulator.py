@@ -9,6 +9,7 @@ f32 = np.float32
 INF = f32(1073741824.0)
 EPS = f32(0.000001)
 LEAF = 0x80000000
+CHAIN = 0x40000000
 
 
 def _fmin(a, b):
@@ -67,27 +68,30 @@ class FlatScene:
         self.blob = flat["blob"]
         self.nodes = self.blob[flat["off_nodes"]:flat["off_tris"]]
         self.tris = self.blob[flat["off_tris"]:flat["off_objlds"]]
-        self.objlds = self.blob[flat["off_objlds"]:]
+        self.objlds = self.blob[flat["off_objlds"]:flat["off_meshes"]]
         self.objects = flat["objects"]
         self.max_stack = 0
 
     def mesh(self, ob, o, d, inv):
         best, best_prim = INF, -1
+        if np.isnan(d).any():
+            return False, best, -1          # a NaN direction fails every triangle test
         hit, rd = box_test(ob["v"][0:3], ob["v"][3:6], o, inv)
-        if not hit or rd > best:
-            return False, best, -1
         cur = int(ob["root_ref"])
+        if not hit or rd > best or ((cur & CHAIN) and not rd < best):
+            return False, best, -1
         stack = []
         while True:
             descended = False
             if cur & LEAF:
-                start, count = cur & 0xFFFFF, (cur >> 20) & 2047
+                start, count = cur & 0xFFFFF, (cur >> 20) & 1023
                 for k in range(count):
                     h, t = tri_test(self.tris, start + k, o, d)
                     if h and t < best:
                         best, best_prim = t, start + k
             else:
-                n = self.nodes[4 * cur:4 * cur + 4].reshape(16)
+                ni = cur & 0x3FFFFFFF
+                n = self.nodes[4 * ni:4 * ni + 4].reshape(16)
                 lh, ld = box_test(n[0:3], n[3:6], o, inv)
                 rh, rdist = box_test(n[6:9], n[9:12], o, inv)
                 lref, rref = int(n[12:13].view(np.uint32)[0]), int(n[13:14].view(np.uint32)[0])
@@ -109,7 +113,7 @@ class FlatScene:
             found = False
             while stack:
                 ref, dd = stack.pop()
-                if not dd > best:
+                if (dd < best) if (ref & CHAIN) else (not dd > best):
                     cur, found = ref, True
                     break
             if not found:
@@ -181,11 +185,12 @@ class FlatScene:
         while todo:
             ref = todo.pop()
             if ref & LEAF:
-                c = (ref >> 20) & 2047
+                c = (ref >> 20) & 1023
                 if c:
                     hist[min(c, hist_len - 1)] += 1
             else:
-                n = self.nodes[4 * ref:4 * ref + 4].reshape(16)
+                ni = ref & 0x3FFFFFFF
+                n = self.nodes[4 * ni:4 * ni + 4].reshape(16)
                 todo.append(int(n[12:13].view(np.uint32)[0]))
                 todo.append(int(n[13:14].view(np.uint32)[0]))
         return hist

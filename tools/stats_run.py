@@ -1,0 +1,36 @@
+"""Section statistics of the render kernel (development tool).  Needs the -DRT_STATS build:
+   python -c "import importlib; importlib.import_module('ray-tracer_amd.build').build_variant('stats', ['-DRT_STATS'])"
+   RT_AMD_LIB=ray-tracer_amd/libraytracer_amd_stats.so python tools/stats_run.py monkey 16"""
+import ctypes as C, importlib, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rt = importlib.import_module("ray-tracer_amd")
+name = sys.argv[1] if len(sys.argv) > 1 else "monkey"
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+W, H = 1920, 1080
+objs, sky = rt.scenes.CONFIG_SCENES[name]()
+ctx = rt.Context(0)
+scene = ctx.commit(rt.SceneObjects(objs))
+out = torch.empty((H, W, 3), device="cuda:0")
+rt.render_device(ctx, scene, rt.Camera(W, H), rt.RenderData(spp, 8, True, sky), 12345, 0, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+ms = ctx.last_kernel_ms()
+buf = (C.c_uint64 * 24)()
+rt.lib().rt_debug_read_stats(ctx._h, buf)
+names = ["ITER", "SHADE", "SHADE_HIT", "FETCH", "GEN", "MESH", "MESH_START", "WORK_ITER", "NODE", "LEAF_TRI", "POP", "DONE_MESH"]
+cost = {"ITER": 20, "SHADE": 30, "SHADE_HIT": 700, "GEN": 300, "MESH": 40, "WORK_ITER": 15, "NODE": 75, "LEAF_TRI": 95, "POP": 12}
+print("%s %dx%d spp=%d: %.2f ms, %.1f Msamples/s  (info %s)" % (name, W, H, spp, ms, W * H * spp / ms / 1e3, scene.info()))
+samples = W * H * spp
+tot_slots = tot_useful = 0
+for i, n in enumerate(names):
+    ex, ln = buf[2 * i], buf[2 * i + 1]
+    c = cost.get(n, 0)
+    tot_slots += ex * 64 * c
+    tot_useful += ln * c
+    if ex:
+        print("  %-10s wave-execs %12d  lanes/exec %5.1f  lane-execs/sample %7.3f  est. slots %5.1f%%" % (n, ex, ln / ex, ln / samples, 0))
+print("  estimated lane utilisation (cost-weighted): %.3f" % (tot_useful / max(tot_slots, 1)))
+for i, n in enumerate(names):
+    ex = buf[2 * i]; c = cost.get(n, 0)
+    if ex and c:
+        print("    %-10s share of issued slots %5.1f%%  (util %.2f)" % (n, 100.0 * ex * 64 * c / tot_slots, buf[2 * i + 1] / ex / 64))
