@@ -49,5 +49,17 @@ def build(force=False, verbose=False):
     return LIB
 
 
+EXAMPLE = os.path.join(HERE, "host", "example_main")
+
+
+def build_example():
+    """The C++ host-side mirror (host/raytracer.hpp) compiled into a small program with g++."""
+    build()
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", os.path.join(HERE, "host", "example_main.cpp"), "-o", EXAMPLE,
+           "-L" + HERE, "-lraytracer_amd", "-Wl,-rpath," + HERE, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+    subprocess.check_call(cmd)
+    return EXAMPLE
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -1,0 +1,48 @@
+/*
+ * example_main.cpp — what the reference's main() (src/main.cu:401-432) looks like on top of
+ * raytracer.hpp, minus the SFML window: build a scene with the reference's factories, render
+ * progressive frames, write the float->RGBA8 result (src/main.cu:343-371) as a binary PPM.
+ *
+ *   example_main <models_dir> <scene 0|1> <width> <height> <frames> <out.ppm>
+ *
+ * Build:  g++ -std=c++17 -O2 example_main.cpp -L.. -lraytracer_amd -Wl,-rpath,'$ORIGIN/..'
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "raytracer.hpp"
+
+using namespace rtamd;
+
+int main(int argc, char **argv)
+{
+    if (argc < 7) {
+        std::fprintf(stderr, "usage: %s <models_dir> <scene 0|1> <width> <height> <frames> <out.ppm>\n", argv[0]);
+        return 2;
+    }
+    const std::string models = argv[1];
+    const int scene_num = std::atoi(argv[2]), W = std::atoi(argv[3]), H = std::atoi(argv[4]), frames = std::atoi(argv[5]);
+    try {
+        SceneObjects mesh_data(scene_num, models);                 /* init(): src/main.cu:389-398 */
+        RenderData render_data(100, 5, true, mesh_data.use_sky ? Vec3(0.8f, 1, 1) : Vec3(0, 0, 0));
+        Camera camera(W, H);
+        Renderer renderer(0);
+        renderer.set_scene(mesh_data);
+        VariableRenderData data{0, std::vector<float>((size_t)W * (size_t)H * 3, 0.0f)};
+        for (int f = 0; f < frames; f++) {
+            renderer.render(camera, render_data, &data, 12345 + f);   /* get_time() in the reference */
+            std::printf("frame %d: %.2f ms\n", data.frame_num, renderer.last_kernel_ms());
+        }
+        std::vector<uint8_t> rgba = parse_pixel_colours(data.previous_render, W, H);
+        FILE *fp = std::fopen(argv[6], "wb");
+        if (!fp) throw std::runtime_error("cannot open output file");
+        std::fprintf(fp, "P6\n%d %d\n255\n", W, H);
+        for (size_t i = 0; i < (size_t)W * (size_t)H; i++) std::fwrite(&rgba[4 * i], 1, 3, fp);
+        std::fclose(fp);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

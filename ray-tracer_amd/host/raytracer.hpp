@@ -1,0 +1,327 @@
+/*
+ * raytracer.hpp — C++ host-side mirror of the reference's scene / camera / render interface,
+ * header-only over the C ABI (include/rt_amd.h, libraytracer_amd.so).
+ *
+ * A reference scene transcribes 1:1: the class and factory names, argument order and error
+ * behaviour are the reference's (file:line cited per item, relative to the reference
+ * checkout); what happens behind them is not.  Differences a caller sees:
+ *   - image size, camera pose, spp, bounce limit, scene and seed are run-time values, not
+ *     compile-time constants (SURVEY.md §5 "config / flags");
+ *   - no __constant__ globals: Camera, RenderData and the committed scene are passed to
+ *     render();
+ *   - errors from the device layer are std::runtime_error("Error from HIP (<what>): <detail>")
+ *     (reference: "Error from CUDA (...)", src/utils.cu:5-10).
+ */
+#ifndef RAYTRACER_AMD_HPP
+#define RAYTRACER_AMD_HPP
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+
+namespace rtamd {
+
+/* src/utils.cu:13-163 (host subset) */
+struct Vec3 {
+    float x = 0, y = 0, z = 0;
+    Vec3() {}
+    Vec3(float vx, float vy, float vz) : x(vx), y(vy), z(vz) {}
+    Vec3 operator+(Vec3 o) const { return Vec3(x + o.x, y + o.y, z + o.z); }
+    Vec3 operator-(Vec3 o) const { return Vec3(x - o.x, y - o.y, z - o.z); }
+    Vec3 operator*(float s) const { return Vec3(x * s, y * s, z * s); }
+    Vec3 operator/(float s) const { return Vec3(x / s, y / s, z / s); }
+    const float *data() const { return &x; }
+};
+
+/* src/utils.cu:166-185 */
+struct Vec2 {
+    float x = 0, y = 0;
+    Vec2() {}
+    Vec2(float vx, float vy) : x(vx), y(vy) {}
+};
+
+/* src/objects.cu:19-22 */
+struct Vertex {
+    Vec3 world_point;
+    Vec2 texture_point;
+};
+
+/* src/material.cu:4-125 */
+class Texture {
+public:
+    static const int COLOUR = 0, GRADIENT = 1, CHECKERBOARD = 2, IMAGE = 3;
+    int type = COLOUR;
+    Vec3 colour, light, dark;
+    int num_squares = 0;
+
+    static Texture create_const_colour(Vec3 texture_colour) { Texture t; t.type = COLOUR; t.colour = texture_colour; return t; }
+    static Texture create_gradient() { Texture t; t.type = GRADIENT; return t; }
+    static Texture create_checkerboard(Vec3 light_colour, Vec3 dark_colour, int num_sq)
+    {
+        Texture t; t.type = CHECKERBOARD; t.light = light_colour; t.dark = dark_colour; t.num_squares = num_sq; return t;
+    }
+};
+
+/* src/material.cu:128-186 */
+class Material {
+public:
+    static const int STANDARD = 0, EMISSIVE = 1, REFRACTIVE = 2;
+    rt_material c{};
+
+    static Material create_standard(Texture mat_tex, float smoothness_val)
+    {
+        Material m;
+        switch (mat_tex.type) {
+            case Texture::COLOUR: rt_material_standard(&m.c, mat_tex.colour.data(), smoothness_val); break;
+            case Texture::GRADIENT: rt_material_gradient(&m.c, smoothness_val); break;
+            case Texture::CHECKERBOARD: rt_material_checkerboard(&m.c, mat_tex.light.data(), mat_tex.dark.data(), mat_tex.num_squares, smoothness_val); break;
+            default: throw std::logic_error("IMAGE textures are not supported yet");
+        }
+        return m;
+    }
+    static Material create_emissive(Vec3 emit_colour, float emit_strength)
+    {
+        Material m;
+        rt_material_emissive(&m.c, emit_colour.data(), emit_strength);
+        return m;
+    }
+    static Material create_refractive(Texture mat_tex, float n)
+    {
+        Material m;
+        rt_material_standard(&m.c, mat_tex.colour.data(), 1.0f);   /* smoothness = 1, src/material.cu:182 */
+        m.c.type = RT_MAT_REFRACTIVE;
+        m.c.refractive_index = n;
+        return m;
+    }
+};
+
+/* src/obj_read.cu:47-147 */
+class ObjFileMesh {
+public:
+    explicit ObjFileMesh(const std::string &filename)
+    {
+        rt_status st = rt_obj_load(filename.c_str(), &h_);
+        if (st == RT_ERR_IO) throw std::runtime_error("Could not find file to open.");   /* :10 */
+        if (st != RT_OK) throw std::runtime_error("Could not parse " + filename);
+    }
+    ~ObjFileMesh() { rt_obj_destroy(h_); }
+    ObjFileMesh(const ObjFileMesh &) = delete;
+    ObjFileMesh &operator=(const ObjFileMesh &) = delete;
+    ObjFileMesh(ObjFileMesh &&o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+
+    void enlarge(float scale_fact) { rt_obj_enlarge(h_, scale_fact); }
+    void rotate(float x_angle, float y_angle, float z_angle) { rt_obj_rotate(h_, x_angle, y_angle, z_angle); }
+    void translate(float offset_x, float offset_y, float offset_z) { rt_obj_translate(h_, offset_x, offset_y, offset_z); }
+    int num_vertices() const { return rt_obj_num_vertices(h_); }
+    int num_faces() const { return rt_obj_num_faces(h_); }
+    const rt_obj *handle() const { return h_; }
+
+private:
+    rt_obj *h_ = nullptr;
+};
+
+/* The scene's object list: std::vector<Object> + Object::create_* (src/objects.cu:845-906,
+ * src/main.cu:94-296).  Objects are appended in call order. */
+class SceneObjects {
+public:
+    bool use_sky = true;
+
+    SceneObjects()
+    {
+        if (rt_scene_builder_create(&b_) != RT_OK) throw std::bad_alloc();
+    }
+    /* SceneObjects(int test_scene) src/main.cu:100-122: scenes 0 and 1 (2 needs an image texture,
+     * 3 and 4 need the refractive material; both are later rows of SURVEY.md §8(f)) */
+    SceneObjects(int test_scene, const std::string &models_dir) : SceneObjects()
+    {
+        switch (test_scene) {
+            case 0: monkey_test_scene(models_dir); break;
+            case 1: reflection_test_scene(); break;
+            case 2: case 3: case 4: throw std::logic_error("this test scene needs a material that is not supported yet");
+            default: throw std::domain_error("Test scene must be number between 0 and 3 (inclusive).\n");   /* :118 */
+        }
+    }
+    ~SceneObjects() { rt_scene_builder_destroy(b_); }
+    SceneObjects(const SceneObjects &) = delete;
+    SceneObjects &operator=(const SceneObjects &) = delete;
+
+    void create_sphere(Vec3 center, float radius, const Material &mat) { check(rt_scene_add_sphere(b_, center.data(), radius, &mat.c)); }
+    void create_triangle(Vec3 p1, Vec3 p2, Vec3 p3, const Material &mat) { check(rt_scene_add_triangle(b_, p1.data(), p2.data(), p3.data(), &mat.c)); }
+    void create_triangle(Vertex p1, Vertex p2, Vertex p3, const Material &mat)
+    {
+        const float p[9] = {p1.world_point.x, p1.world_point.y, p1.world_point.z, p2.world_point.x, p2.world_point.y, p2.world_point.z,
+                            p3.world_point.x, p3.world_point.y, p3.world_point.z};
+        const float uv[6] = {p1.texture_point.x, p1.texture_point.y, p2.texture_point.x, p2.texture_point.y, p3.texture_point.x, p3.texture_point.y};
+        check(rt_scene_add_triangle_uv(b_, p, uv, &mat.c));
+    }
+    void create_quad(Vec3 p1, Vec3 p2, Vec3 p3, Vec3 p4, const Material &mat) { check(rt_scene_add_quad(b_, p1.data(), p2.data(), p3.data(), p4.data(), &mat.c)); }
+    void create_one_way_quad(Vec3 p1, Vec3 p2, Vec3 p3, Vec3 p4, bool invert_normal, const Material &mat)
+    {
+        check(rt_scene_add_one_way_quad(b_, p1.data(), p2.data(), p3.data(), p4.data(), invert_normal ? 1 : 0, &mat.c));
+    }
+    void create_cuboid(Vec3 tl_near_pos, float width, float height, float depth, const Material &mat)
+    {
+        check(rt_scene_add_cuboid(b_, tl_near_pos.data(), width, height, depth, &mat.c));
+    }
+    /* SceneObjects::create_mesh src/main.cu:127-148 */
+    void create_mesh(const ObjFileMesh &obj, const Material &mat) { check(rt_scene_add_obj_mesh(b_, obj.handle(), &mat.c)); }
+
+    /* create_cornell_box src/main.cu:252-288 */
+    void create_cornell_box(Vec3 tl_near_pos, float width, float height, float depth, float light_width)
+    {
+        use_sky = false;
+        Material floor = Material::create_standard(Texture::create_checkerboard(Vec3(0.1f, 0.8f, 0.1f), Vec3(0.1f, 0.5f, 0.1f), 8), 0);
+        Material l_wall = Material::create_standard(Texture::create_const_colour(Vec3(1, 0.2f, 0.2f)), 0);
+        Material r_wall = Material::create_standard(Texture::create_const_colour(Vec3(0.3f, 0.3f, 1)), 0);
+        Material back = Material::create_standard(Texture::create_const_colour(Vec3(0.2f, 0.2f, 0.2f)), 0);
+        Material roof = Material::create_standard(Texture::create_const_colour(Vec3(0.9f, 0.9f, 0.9f)), 0);
+        Material front = Material::create_standard(Texture::create_const_colour(Vec3(1, 1, 1)), 0);
+        Vec3 w(width, 0, 0), h(0, height, 0), d(0, 0, depth), p = tl_near_pos;
+        create_quad(p - h, p - h + w, p - h + w + d, p - h + d, floor);
+        create_quad(p, p - h, p - h + d, p + d, l_wall);
+        create_quad(p + w, p + w - h, p + w - h + d, p + w + d, r_wall);
+        create_quad(p + d, p + w + d, p + w - h + d, p - h + d, back);
+        create_quad(p, p + d, p + w + d, p + w, roof);
+        create_one_way_quad(p, p + w, p + w - h, p - h, false, front);
+        Material light_mat = Material::create_emissive(Vec3(1, 1, 1), 6);
+        Vec3 light_tl(p.x + width / 2 - light_width / 2, p.y, p.z + depth / 2 - light_width / 2);
+        create_cuboid(light_tl, light_width, 0.04f, light_width, light_mat);
+    }
+
+    int num_objects() const { return rt_scene_builder_num_objects(b_); }
+    const rt_scene_builder *handle() const { return b_; }
+
+private:
+    rt_scene_builder *b_ = nullptr;
+
+    void check(rt_status st)
+    {
+        if (st == RT_OK) return;
+        std::string msg = rt_scene_builder_error(b_);
+        if (st == RT_ERR_UNSUPPORTED) throw std::logic_error(msg);      /* src/main.cu:141 */
+        throw std::invalid_argument(msg);
+    }
+    void monkey_test_scene(const std::string &models_dir)
+    {   /* src/main.cu:150-170 */
+        create_cornell_box(Vec3(-0.5f, 0.5f, 1.2f), 1, 1, 1, 0.5f);
+        ObjFileMesh m(models_dir + "/low_poly_monkey.obj");
+        m.enlarge(0.3f);
+        m.rotate(0, 2.3f, 0);
+        m.translate(0.1f, -0.1f, 1.6f);
+        create_mesh(m, Material::create_standard(Texture::create_const_colour(Vec3(1, 1, 1)), 0));
+        create_sphere(Vec3(-0.25f, -0.25f, 1.95f), 0.25f, Material::create_standard(Texture::create_const_colour(Vec3(0.8f, 0.8f, 0.8f)), 1));
+    }
+    void reflection_test_scene()
+    {   /* src/main.cu:172-187 */
+        create_cornell_box(Vec3(-0.5f, 0.5f, 1.2f), 1, 1, 1, 0.5f);
+        Texture t = Texture::create_const_colour(Vec3(1, 1, 1));
+        create_sphere(Vec3(-0.2f, 0.2f, 1.7f), 0.15f, Material::create_standard(t, 0));
+        create_sphere(Vec3(0.2f, 0.2f, 1.7f), 0.15f, Material::create_standard(t, 0.33f));
+        create_sphere(Vec3(-0.2f, -0.2f, 1.7f), 0.15f, Material::create_standard(t, 0.66f));
+        create_sphere(Vec3(0.2f, -0.2f, 1.7f), 0.15f, Material::create_standard(t, 1));
+    }
+};
+
+/* src/camera.cu:32-108; assign_constant_mem() becomes the POD this object carries */
+class Camera {
+public:
+    rt_camera c{};
+    Camera(int width, int height) { rt_camera_default(width, height, &c); }                       /* pose constants of :34-41 */
+    Camera(int width, int height, Vec3 pos, float fov, float focal_len, float x_rot, float y_rot, float z_rot)
+    {
+        rt_camera_make(width, height, pos.data(), fov, focal_len, x_rot, y_rot, z_rot, &c);
+    }
+};
+
+/* src/raytracer.cu:4-12 with the defaults of RenderSettings src/main.cu:318-330 */
+struct RenderData {
+    rt_render_settings c{};
+    RenderData(int rays_per_pixel = 100, int reflection_limit = 5, bool antialias = true, Vec3 sky_colour = Vec3(0, 0, 0))
+    {
+        c.rays_per_pixel = rays_per_pixel;
+        c.reflection_limit = reflection_limit;
+        c.antialias = antialias ? 1 : 0;
+        c.sky_colour[0] = sky_colour.x; c.sky_colour[1] = sky_colour.y; c.sky_colour[2] = sky_colour.z;
+    }
+};
+
+/* src/dispatch.cu:111-115 */
+struct VariableRenderData {
+    int frame_num;
+    std::vector<float> previous_render;
+};
+
+/* One GPU: owns the HIP context and the uploaded scene (replaces the __constant__ symbols and
+ * allocate_constant_mem, src/dispatch.cu:104-108). */
+class Renderer {
+public:
+    explicit Renderer(int device = 0)
+    {
+        rt_status st = rt_ctx_create(device, &ctx_);
+        if (st == RT_ERR_NO_DEVICE) throw std::runtime_error("Error from HIP (creating context): no usable GPU; there is no CPU fallback");
+        if (st != RT_OK) throw std::runtime_error("Error from HIP (creating context): status " + std::to_string(st));
+    }
+    ~Renderer()
+    {
+        rt_scene_destroy(scene_);
+        rt_ctx_destroy(ctx_);
+    }
+    Renderer(const Renderer &) = delete;
+    Renderer &operator=(const Renderer &) = delete;
+
+    void set_scene(const SceneObjects &objs)
+    {
+        rt_scene_destroy(scene_);
+        scene_ = nullptr;
+        check(rt_scene_commit(ctx_, objs.handle(), &scene_));
+    }
+    /* render(VariableRenderData*, int) src/dispatch.cu:156-163 */
+    void render(const Camera &cam, const RenderData &rd, VariableRenderData *data, int current_time_ms)
+    {
+        if (data->previous_render.size() != (size_t)cam.c.width * (size_t)cam.c.height * 3) throw std::invalid_argument("previous_render has the wrong size");
+        int32_t fn = data->frame_num;
+        check(rt_render(ctx_, scene_, &cam.c, &rd.c, current_time_ms, &fn, data->previous_render.data()));
+        data->frame_num = fn;
+    }
+    float last_kernel_ms()
+    {
+        float ms = 0;
+        check(rt_last_kernel_ms(ctx_, &ms));
+        return ms;
+    }
+
+private:
+    rt_ctx *ctx_ = nullptr;
+    rt_scene *scene_ = nullptr;
+    void check(rt_status st)
+    {
+        if (st == RT_OK) return;
+        std::string msg = rt_last_error(ctx_);
+        if (st == RT_ERR_UNSUPPORTED) throw std::logic_error(msg);
+        if (st == RT_ERR_INVALID) throw std::invalid_argument(msg);
+        throw std::runtime_error(msg);                                  /* check_cuda_error src/utils.cu:5-10 */
+    }
+};
+
+/* parse_pixel_colours src/main.cu:343-371: int(px*255), clamp, alpha 255 */
+inline std::vector<uint8_t> parse_pixel_colours(const std::vector<float> &pixel_colours, int width, int height)
+{
+    std::vector<uint8_t> out((size_t)width * (size_t)height * 4);
+    for (size_t i = 0; i < (size_t)width * (size_t)height; i++) {
+        for (int k = 0; k < 3; k++) {
+            int colour = (int)(pixel_colours[3 * i + k] * 255);
+            if (colour > 255) colour = 255; else if (colour < 0) colour = 0;
+            out[4 * i + k] = (uint8_t)colour;
+        }
+        out[4 * i + 3] = 255;
+    }
+    return out;
+}
+
+}  // namespace rtamd
+
+#endif

@@ -223,3 +223,29 @@ def test_argument_errors(rt, ctx):
         rt.render_device(ctx, scene, rt.Camera(16, 16), rt.RenderData(1, 1, True, sky), 0, 0, buf.data_ptr(), band_first=2, band_stride=2)
     with pytest.raises(ValueError):
         rt.render_device(ctx, scene, rt.Camera(16, 16), rt.RenderData(-1, 1, True, sky), 0, 0, buf.data_ptr())
+
+
+def test_cpp_host_mirror_end_to_end(rt, orc, models_dir, tmp_path):
+    """host/raytracer.hpp + example_main.cpp: the reference's main() flow (SceneObjects(scene),
+    RenderSettings defaults 100 spp / 5 bounces, progressive frames, float->RGBA8) in C++ over
+    the C ABI, compared with the oracle's progressive frames converted the same way."""
+    import ctypes as C
+    import subprocess
+    bmod = __import__("importlib").import_module("ray-tracer_amd.build")
+    exe = bmod.build_example()
+    W, H, frames = 80, 64, 2
+    for scene_num, name in ((1, "reference_scene1"), (0, "reference_scene0")):
+        out = tmp_path / ("s%d.ppm" % scene_num)
+        subprocess.check_call([exe, models_dir, str(scene_num), str(W), str(H), str(frames), str(out)], timeout=300)
+        raw = out.read_bytes()
+        header = ("P6\n%d %d\n255\n" % (W, H)).encode()
+        assert raw.startswith(header)
+        got = np.frombuffer(raw[len(header):], np.uint8).reshape(H, W, 3)
+        objs, sky = rt.scenes.CONFIG_SCENES[name]()
+        o = orc.Scene(objs, orc.MATH_DET, models_dir)
+        prev = None
+        for f in range(frames):
+            prev = o.render(rt.Camera(W, H).floats(), W, H, 100, 5, sky, time_ms=12345 + f, frame_num=f, prev=prev)
+        want = np.zeros((H, W, 4), np.uint8)
+        orc.lib().orc_to_rgba8(prev.ctypes.data_as(C.POINTER(C.c_float)), W, H, want.ctypes.data_as(C.POINTER(C.c_uint8)))
+        assert np.array_equal(got, want[:, :, :3]), name
