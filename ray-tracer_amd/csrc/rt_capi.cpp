@@ -121,7 +121,8 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
 
     /* workgroup size: the largest one whose LDS (scene + per-lane traversal stacks) fits */
     const size_t blob_bytes = s->flat.blob.size() * sizeof(rt_f4);
-    const size_t per_thread = s->flat.has_mesh ? (size_t)s->flat.stack_entries * 8 : 0;
+    /* one spare stack entry: the traversal loop always writes the slot above the top */
+    const size_t per_thread = s->flat.has_mesh ? (size_t)(s->flat.stack_entries + 1) * 8 : 0;
     const int candidates[4] = {1024, 768, 512, 256};
     s->threads = 0;
     if (!s->flat.has_mesh) {
@@ -229,6 +230,7 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     a.off_tris = scene->flat.off_tris;
     a.off_objlds = scene->flat.off_objlds;
     a.off_meshes = scene->flat.off_meshes;
+    a.off_objtab = scene->flat.off_objtab;
     a.num_meshes = scene->flat.num_meshes;
     a.stack_entries = scene->flat.stack_entries;
     a.work_threshold = ctx->work_threshold;

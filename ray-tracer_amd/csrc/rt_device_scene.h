@@ -10,8 +10,8 @@
  *     tris    48 B  p0, side1, side2, unit normal            (reference src/objects.cu:175-186)
  *     objlds  48 B  per top-level object: what shading needs for a per-lane object index
  *     meshes  32 B  per mesh object: root box, root reference, object index
- *   global memory, read with wave-uniform (scalar) loads while looping over the object list:
- *     objects 48 B  type, primitive range / BVH root, sphere or root-box constants
+ *     objtab  48 B  the object list (rt_object) every lane walks in the same order: wave-uniform
+ *                   LDS reads (broadcast) instead of vector global loads
  *   global memory, read once per textured hit:
  *     tri_uv  24 B  per-triangle texture coordinates (only when a material needs UVs)
  *
@@ -101,7 +101,7 @@ typedef struct {
     int32_t num_objects;
     const rt_f4 *blob;             /* LDS-staged part */
     int32_t blob_f4;               /* its size in 16-byte units */
-    int32_t off_nodes, off_tris, off_objlds, off_meshes;   /* section offsets in 16-byte units */
+    int32_t off_nodes, off_tris, off_objlds, off_meshes, off_objtab;   /* section offsets in 16-byte units */
     int32_t num_meshes;
     int32_t stack_entries;         /* per-lane traversal stack depth (LDS) */
     int32_t work_threshold;        /* run traversal steps while at least this many lanes traverse */

@@ -610,7 +610,9 @@ std::string rt_flatten(const rt_scene_builder &b, FlatScene &out)
     out.off_objlds = out.off_tris + (int)(n_tris * 3);
     out.off_meshes = out.off_objlds + (int)(b.objs.size() * 3);
     out.num_meshes = (int)n_meshes;
-    out.blob.resize((size_t)out.off_meshes + n_meshes * 2);
+    out.off_objtab = out.off_meshes + (int)(n_meshes * 2);
+    static_assert(sizeof(rt_object) == 48, "rt_object is three 16-byte units");
+    out.blob.resize((size_t)out.off_objtab + b.objs.size() * 3);
     out.stack_entries = 1;
     out.num_nodes = (int)n_nodes;
     out.num_tris = (int)n_tris;
@@ -669,6 +671,7 @@ std::string rt_flatten(const rt_scene_builder &b, FlatScene &out)
         rec[1] = rt_f4{B[0], B[1], B[2], rt_u2f(packed)};
         rec[2] = rt_f4{o.v[0], o.v[1], o.v[2], o.v[3]};
         out.objects.push_back(ro);
+        std::memcpy(&out.blob[(size_t)out.off_objtab + oi * 3], &ro, sizeof ro);
         node_base += o.nodes.size();
         tri_base += o.tris.size();
     }

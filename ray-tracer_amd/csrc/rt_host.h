@@ -43,7 +43,7 @@ struct rt_obj {
 /* flattened scene, ready to upload */
 struct FlatScene {
     std::vector<rt_f4> blob;
-    int off_nodes = 0, off_tris = 0, off_objlds = 0, off_meshes = 0;
+    int off_nodes = 0, off_tris = 0, off_objlds = 0, off_meshes = 0, off_objtab = 0;
     int num_meshes = 0;
     int stack_entries = 1;                       /* per-lane traversal stack depth this scene needs */
     std::vector<rt_object> objects;

@@ -81,8 +81,8 @@ struct Lds {
     const v4f *tris;
     const v4f *objs;
     const v4f *meshes;
-    float *stack_d;      /* [stack_entries][NT] entry distance of the deferred sibling */
-    uint32_t *stack_r;   /* [stack_entries][NT] its reference */
+    const v4f *objtab;   /* the object list (rt_object, 3 x 16 B each), read with wave-uniform addresses */
+    uint2 *stack;        /* [stack_entries + 1][NT] deferred sibling: (entry distance bits, reference) */
 };
 
 /* BoundingBox::ray_hits src/objects.cu:404-434.  fminf/fmaxf drop a NaN operand like CUDA's
@@ -156,8 +156,8 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
     L.tris = lds_raw + a.off_tris;
     L.objs = lds_raw + a.off_objlds;
     L.meshes = lds_raw + a.off_meshes;
-    L.stack_d = (float *)(lds_raw + a.blob_f4);
-    L.stack_r = (uint32_t *)(L.stack_d + a.stack_entries * NT);
+    L.objtab = lds_raw + a.off_objtab;
+    L.stack = (uint2 *)(lds_raw + a.blob_f4);
     __syncthreads();
 
     const V3 cam_pos = v3(a.cam[0], a.cam[1], a.cam[2]);
@@ -374,7 +374,13 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
              * rule made explicit: smaller distance, or equal distance and larger list index. */
             best_t = RT_INF_F; best_obj = -1; best_prim = -1;
             for (int i = 0; i < a.num_objects; i++) {
-                const rt_object ob = a.objects[i];
+                /* rt_object from LDS: every lane reads the same address (broadcast) */
+                const v4f ob0 = L.objtab[3 * i], ob1 = L.objtab[3 * i + 1], ob2 = L.objtab[3 * i + 2];
+                rt_object ob;
+                ob.type = (int32_t)__float_as_uint(ob0.x); ob.prim_start = (int32_t)__float_as_uint(ob0.y);
+                ob.need_uv = (int32_t)__float_as_uint(ob0.z); ob.root_ref = __float_as_uint(ob0.w);
+                ob.v[0] = ob1.x; ob.v[1] = ob1.y; ob.v[2] = ob1.z; ob.v[3] = ob1.w;
+                ob.v[4] = ob2.x; ob.v[5] = ob2.y; ob.v[6] = ob2.z; ob.v[7] = ob2.w;
                 bool hit = false;
                 float t = RT_INF_F;
                 int prim = -1;
@@ -461,34 +467,34 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                      * waves/SIMD an LDS-resident scene allows that latency is not hidden.) */
                     bool at_leaf = (cur & RT_REF_LEAF) != 0u;
                     if (!at_leaf) {
+                        /* The body is branch-free: the deferred sibling is ALWAYS written to the
+                         * slot above the top of the stack (one 8-byte LDS store) and the stack
+                         * pointer moves only when both children are entered, so the only
+                         * divergent branch of the loop is its exit. */
                         for (;;) {
                             RT_STAT(ST_NODE);
                             const v4f *n = L.nodes + 4 * (int)(cur & RT_REF_NODE_MASK);
                             v4f q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
                             float ld, rdist;
-                            bool lh = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, ld);
-                            bool rh2 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, rdist);
-                            uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
-                            bool l_push = lh && ld < w_best;
-                            bool r_push = rh2 && rdist < w_best;
-                            bool l_first = ld < rdist;
+                            const bool lh = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, ld);
+                            const bool rh2 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, rdist);
+                            const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+                            const bool l_push = lh && ld < w_best;
+                            const bool r_push = rh2 && rdist < w_best;
+                            const bool l_first = ld < rdist;
                             /* "first" is pushed first and therefore visited second */
-                            uint32_t first_ref = l_first ? lref : rref, second_ref = l_first ? rref : lref;
-                            float first_d = l_first ? ld : rdist;
-                            bool first_push = l_first ? l_push : r_push, second_push = l_first ? r_push : l_push;
-                            if (second_push) {
-                                if (first_push) {
-                                    L.stack_d[sp * NT + tid] = first_d;
-                                    L.stack_r[sp * NT + tid] = first_ref;
-                                    sp++;
-                                }
-                                cur = second_ref;       /* popped immediately: its distance is still < best */
-                            } else if (first_push) {
-                                cur = first_ref;
-                            } else {
-                                break;                  /* nothing entered: pop */
-                            }
-                            if (cur & RT_REF_LEAF) { at_leaf = true; break; }
+                            const uint32_t first_ref = l_first ? lref : rref, second_ref = l_first ? rref : lref;
+                            const float first_d = l_first ? ld : rdist;
+                            const bool first_push = l_first ? l_push : r_push, second_push = l_first ? r_push : l_push;
+                            L.stack[sp * NT + tid] = make_uint2(__float_as_uint(first_d), first_ref);
+                            sp += (first_push && second_push) ? 1 : 0;
+                            /* the child entered now: `second` (popped immediately, its distance is
+                             * still < best) if it was pushed, else `first` */
+                            const uint32_t next = second_push ? second_ref : first_ref;
+                            const bool entered = first_push || second_push;
+                            cur = entered ? next : cur;
+                            at_leaf = entered && (next & RT_REF_LEAF) != 0u;
+                            if (!entered || at_leaf) break;
                         }
                     }
                     if (at_leaf) {
@@ -508,8 +514,9 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                     while (sp > 0) {
                         RT_STAT(ST_POP);
                         sp--;
-                        const float dd = L.stack_d[sp * NT + tid];
-                        const uint32_t rr = L.stack_r[sp * NT + tid];
+                        const uint2 e = L.stack[sp * NT + tid];
+                        const float dd = __uint_as_float(e.x);
+                        const uint32_t rr = e.y;
                         const bool take = (rr & RT_REF_CHAIN) ? (dd < w_best) : !(dd > w_best);
                         if (take) { cur = rr; found = true; break; }
                     }
