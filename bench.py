@@ -79,6 +79,10 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--limit", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo + --share-gpu rehearses N ranks on ONE GPU (RCCL refuses duplicate devices)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
+    ap.add_argument("--check", action="store_true", help="rank 0 also renders the frame alone and checks the gathered frame equals it bit for bit")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,11 +92,16 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU; the HIP path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     rt = importlib.import_module("ray-tracer_amd")
     dm = importlib.import_module("ray-tracer_amd.distributed")
@@ -182,6 +191,11 @@ def main():
             out["gpu_over_cpu"] = value / cb["value"]
         if frame is not None:
             out["frame_mean"] = float(frame.mean().item())
+            if args.check:
+                alone = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+                rt.render_device(ctx, scene, cam, rd, 12345, 0, alone.data_ptr(), stream=stream)
+                torch.cuda.synchronize()
+                out["gathered_equals_single_launch"] = bool(torch.equal(frame.contiguous().view(torch.int32), alone.view(torch.int32)))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -41,6 +41,14 @@ def gather_frame(local, width, height, band_rows, rank, world, dst=0, group=None
     bands are padding).  Returns the assembled frame on ``dst`` and None elsewhere."""
     if world == 1:
         return local[:height] if band_rows * num_bands(height, band_rows) != height else local
+    if dist.get_backend(group) == "gloo" and local.is_cuda:
+        # rehearsal mode (several ranks sharing one GPU, which RCCL refuses): gloo moves host memory
+        host = local.cpu()
+        host_out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype) if rank == dst else None
+        dist.gather(host, gather_list=list(host_out.unbind(0)) if rank == dst else None, dst=dst, group=group)
+        if rank != dst:
+            return None
+        return assemble(host_out.to(local.device), width, height, band_rows, world)
     gather_list = None
     if rank == dst:
         if out is None:

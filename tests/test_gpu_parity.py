@@ -249,3 +249,25 @@ def test_cpp_host_mirror_end_to_end(rt, orc, models_dir, tmp_path):
         want = np.zeros((H, W, 4), np.uint8)
         orc.lib().orc_to_rgba8(prev.ctypes.data_as(C.POINTER(C.c_float)), W, H, want.ctypes.data_as(C.POINTER(C.c_uint8)))
         assert np.array_equal(got, want[:, :, :3]), name
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N>1 path end to end (torch.distributed.run, band partition, gather, JSON
+    contract) with two ranks sharing cuda:0 over gloo — RCCL refuses duplicate devices, so this
+    is the closest a one-GPU box gets to the multi-GPU run; the gathered frame must equal the
+    single-launch frame bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--spp", "8", "--backend", "gloo", "--share-gpu", "--check", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["unit"] == "Msamples/s" and j["value"] > 0
+    assert j["gathered_equals_single_launch"] is True
+    assert "roofline" in j and j["roofline"]["bound"] == "hbm"
