@@ -52,6 +52,8 @@ typedef struct rt_material {
     int32_t need_uv;
     float emitted_light[3];    /* colour * strength, :170 */
     float refractive_index;
+    int32_t img_w, img_h;      /* Texture::create_image :42-51 */
+    const float *img_rgb;      /* img_w*img_h*3 floats, row-major; copied when the object is added */
 } rt_material;
 
 /* Material::create_standard(Texture::create_const_colour(colour), smoothness)  :157-165 */
@@ -63,6 +65,18 @@ void rt_material_gradient(rt_material *m, float smoothness);
 /* Material::create_emissive(colour, strength) :167-173.  The reference leaves smoothness,
  * need_uv and texture uninitialised there; this ABI defines them as 0 / false / COLOUR(0,0,0). */
 void rt_material_emissive(rt_material *m, const float colour[3], float strength);
+/* Material::create_refractive(Texture::create_const_colour(colour), n) :175-185 (smoothness = 1) */
+void rt_material_refractive(rt_material *m, const float colour[3], float n);
+/* Material::create_standard(Texture::create_image(width, height, rgb), smoothness) :42-51;
+ * nearest-texel lookup :119-124 (an out-of-range texel index is clamped, the reference reads
+ * out of bounds) */
+void rt_material_image(rt_material *m, int32_t width, int32_t height, const float *rgb, float smoothness);
+/* ImageTexture src/main.cu:40-91: the entry `name` of a baked texture file
+ * (textures/parse_textures.py format: name \n W \n H \n "r g b r g b ... ").  *rgb is malloc'ed;
+ * release it with rt_image_texture_free.  RT_ERR_IO: file missing; RT_ERR_INVALID: name not
+ * found ("Image file not found.", src/main.cu:72) */
+rt_status rt_image_texture_load(const char *parsed_textures_path, const char *name, int32_t *width, int32_t *height, float **rgb);
+void rt_image_texture_free(float *rgb);
 
 /* ---- scene: Object::create_* src/objects.cu:845-906, SceneObjects src/main.cu:94-296 ------ */
 rt_status rt_scene_builder_create(rt_scene_builder **out);

@@ -66,6 +66,7 @@ def lib():
     L.orc_material_checkerboard.argtypes = [C.POINTER(Material), f3, f3, C.c_int, C.c_float]
     L.orc_material_emissive.argtypes = [C.POINTER(Material), f3, C.c_float]
     L.orc_material_refractive.argtypes = [C.POINTER(Material), f3, C.c_float]
+    L.orc_material_image.argtypes = [C.POINTER(Material), C.c_int, C.c_int, f3, C.c_float]
     L.orc_add_sphere.argtypes = [C.c_void_p, f3, C.c_float, C.POINTER(Material)]
     L.orc_add_triangle.argtypes = [C.c_void_p, f3, f3, f3, C.POINTER(Material)]
     L.orc_add_triangle_uv.argtypes = [C.c_void_p, f3, f3, C.POINTER(Material)]
@@ -97,6 +98,9 @@ def lib():
     for n in ("orc_math_logf", "orc_math_cosf", "orc_math_sinf", "orc_math_tanf"):
         getattr(L, n).restype = C.c_float
         getattr(L, n).argtypes = [C.c_float, C.c_int]
+    for n in ("orc_math_asin", "orc_math_acos"):
+        getattr(L, n).restype = C.c_double
+        getattr(L, n).argtypes = [C.c_double, C.c_int]
     L.orc_to_rgba8.argtypes = [f3, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
     _lib = L
     return L
@@ -110,7 +114,7 @@ def _f3(a):
 def make_material(desc):
     """desc: ('standard', colour, smoothness) | ('emissive', colour, strength) |
     ('checkerboard', light, dark, num_squares, smoothness) | ('gradient', smoothness) |
-    ('refractive', colour, n)"""
+    ('refractive', colour, n) | ('image', rgb[h,w,3], smoothness)"""
     L = lib()
     m = Material()
     kind = desc[0]
@@ -129,6 +133,10 @@ def make_material(desc):
     elif kind == "refractive":
         _, p = _f3(desc[1])
         L.orc_material_refractive(C.byref(m), p, C.c_float(desc[2]))
+    elif kind == "image":            # ('image', rgb[h,w,3], smoothness)
+        arr, p = _f3(np.asarray(desc[1], np.float32))
+        L.orc_material_image(C.byref(m), arr.shape[1], arr.shape[0], p, C.c_float(desc[2]))
+        m._keep = arr                # the oracle keeps the pointer
     else:
         raise ValueError(kind)
     return m
@@ -191,6 +199,7 @@ class Scene:
         for o in objects:
             kind = o[0]
             m = make_material(o[-1])
+            self._keep.append(m)
             if kind == "sphere":
                 _, c = _f3(o[1])
                 L.orc_add_sphere(self._h, c, C.c_float(o[2]), C.byref(m))

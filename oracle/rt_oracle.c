@@ -113,6 +113,7 @@ typedef struct {
     v3 origin, direction, direction_inv;
     uint32_t *rng;
     int antialias;
+    float current_refractive_index;    /* src/ray.cu:56,144: 1 (air) for every fresh copy of the primary ray */
 } ray_t;
 
 typedef struct { int hits; float dist; v3 point, normal; float u, v; } hit_t;   /* RayHitData src/ray.cu:22-29 */
@@ -156,6 +157,12 @@ void orc_material_emissive(orc_material *m, const float colour[3], float strengt
     m->emitted[2] = colour[2] * strength;
 }
 
+void orc_material_image(orc_material *m, int w, int h, const float *rgb, float smoothness)
+{   /* Texture::create_image :42-51 + create_standard */
+    orc_material_standard(m, ORC_TEX_IMAGE, NULL, smoothness);
+    m->img_w = w; m->img_h = h; m->img_rgb = rgb;
+}
+
 void orc_material_refractive(orc_material *m, const float colour[3], float n)
 {   /* :175-185 */
     memset(m, 0, sizeof *m);
@@ -180,7 +187,11 @@ static inline v3 texture_colour(const orc_material *m, float u, float v)
         case ORC_TEX_IMAGE: {                                           /* :119-124 */
             int uc = (int)((m->img_w - 1) * u);
             int vc = (int)((m->img_h - 1) * v);
-            return v3_from(m->img_rgb + 3 * (vc * m->img_w + uc));
+            int idx = vc * m->img_w + uc;
+            /* the reference indexes unchecked; an out-of-range texel is clamped here (and in the kernel) */
+            if (idx < 0) idx = 0;
+            if (idx > m->img_w * m->img_h - 1) idx = m->img_w * m->img_h - 1;
+            return v3_from(m->img_rgb + 3 * idx);
         }
         default: return v3_make(0, 0, 0);
     }
@@ -231,8 +242,8 @@ static inline hit_t sphere_hit(const object_t *o, const ray_t *ray, orc_stats *s
             h.dist = dist;
             h.point = hp;
             h.normal = v3_normalised(v3_sub(hp, o->center));
-            /* assign_texture_coords :82-97 needs asin/acos: sphere UVs are not restated yet
-             * (SURVEY.md §8(f) rank 2); orc_add_sphere rejects need_uv materials. */
+            /* assign_texture_coords :82-97 (asin / acos) is a pure function of the hit point; it
+             * is evaluated for the winning sphere in rt_oracle_core.inc, where the math binding is */
         }
     }
     return h;
@@ -385,7 +396,7 @@ static inline hit_t object_hit(const object_t *o, const ray_t *ray, orc_stats *s
 
 /* get_ray_collision src/raytracer.cu:24-46 — `<=`: the later object wins ties; the
  * precision_error test is a no-op for accepted hits (App. A.6) but is evaluated as written. */
-static inline hit_t scene_collision(const orc_scene *s, const ray_t *ray, const orc_material **mat, orc_stats *st)
+static inline hit_t scene_collision(const orc_scene *s, const ray_t *ray, const object_t **obj, orc_stats *st)
 {
     hit_t best = hit_miss();
     for (int i = 0; i < s->nobjs; i++) {
@@ -393,7 +404,7 @@ static inline hit_t scene_collision(const orc_scene *s, const ray_t *ray, const 
         if (!h.hits) continue;
         int closest = h.dist <= best.dist;
         int precision_error = (float)(-ORC_EPS < h.dist) < ORC_EPS;      /* (bool)(-eps<d) < eps */
-        if (closest && !precision_error) { best = h; *mat = &s->objs[i].mat; }
+        if (closest && !precision_error) { best = h; *obj = &s->objs[i]; }
     }
     return best;
 }
@@ -404,18 +415,42 @@ static inline hit_t scene_collision(const orc_scene *s, const ray_t *ray, const 
 #define ORC_SUFFIX _libm
 #define ORC_LOGF(x) logf(x)
 #define ORC_COSF(x) cosf(x)
+#define ORC_SINF(x) sinf(x)
+#define ORC_ASINF(x) asinf(x)
+#define ORC_ACOSF(x) acosf(x)
+#define ORC_ASIN(x) asin(x)
+#define ORC_ACOS(x) acos(x)
+#define ORC_POW5(x) pow((x), 5.0)
 #include "rt_oracle_core.inc"
 #undef ORC_SUFFIX
 #undef ORC_LOGF
 #undef ORC_COSF
+#undef ORC_SINF
+#undef ORC_ASINF
+#undef ORC_ACOSF
+#undef ORC_ASIN
+#undef ORC_ACOS
+#undef ORC_POW5
 
 #define ORC_SUFFIX _det
 #define ORC_LOGF(x) rt_logf(x)
 #define ORC_COSF(x) rt_cosf(x)
+#define ORC_SINF(x) rt_sinf(x)
+#define ORC_ASINF(x) rt_asinf(x)
+#define ORC_ACOSF(x) rt_acosf(x)
+#define ORC_ASIN(x) rt_asin(x)
+#define ORC_ACOS(x) rt_acos(x)
+#define ORC_POW5(x) rt_pow5(x)
 #include "rt_oracle_core.inc"
 #undef ORC_SUFFIX
 #undef ORC_LOGF
 #undef ORC_COSF
+#undef ORC_SINF
+#undef ORC_ASINF
+#undef ORC_ACOSF
+#undef ORC_ASIN
+#undef ORC_ACOS
+#undef ORC_POW5
 
 /* ------------------------------------------------------------------------------------------
  * BVH build — src/objects.cu:602-739 (host)
@@ -526,7 +561,6 @@ int orc_scene_num_objects(const orc_scene *s) { return s->nobjs; }
 
 static object_t *scene_new_object(orc_scene *s, int type, const orc_material *m)
 {
-    if (m->type == ORC_MAT_REFRACTIVE) { fprintf(stderr, "rt_oracle: REFRACTIVE materials are not restated yet\n"); abort(); }
     if (m->tex_type == ORC_TEX_IMAGE && m->need_uv && !m->img_rgb) { fprintf(stderr, "rt_oracle: IMAGE texture without data\n"); abort(); }
     if (s->nobjs == s->cap) { s->cap = s->cap ? s->cap * 2 : 16; s->objs = realloc(s->objs, sizeof(object_t) * (size_t)s->cap); }
     object_t *o = &s->objs[s->nobjs++];
@@ -538,7 +572,6 @@ static object_t *scene_new_object(orc_scene *s, int type, const orc_material *m)
 
 void orc_add_sphere(orc_scene *s, const float c[3], float r, const orc_material *m)
 {
-    if (m->need_uv) { fprintf(stderr, "rt_oracle: sphere UVs are not restated yet\n"); abort(); }
     object_t *o = scene_new_object(s, OBJ_SPHERE, m);
     o->center = v3_from(c);
     o->radius = r;
@@ -630,13 +663,13 @@ int orc_trace_one(const orc_scene *s, const float origin[3], const float dir[3],
     ray_t ray; memset(&ray, 0, sizeof ray);
     ray.origin = v3_from(origin);
     ray_change_direction(&ray, v3_from(dir));
-    const orc_material *mat = NULL;
-    hit_t h = scene_collision(s, &ray, &mat, &st);
+    const object_t *ob = NULL;
+    hit_t h = scene_collision(s, &ray, &ob, &st);
     out[0] = h.dist;
     out[1] = h.point.x; out[2] = h.point.y; out[3] = h.point.z;
     out[4] = h.normal.x; out[5] = h.normal.y; out[6] = h.normal.z;
     out[7] = -1;
-    if (h.hits) for (int i = 0; i < s->nobjs; i++) if (mat == &s->objs[i].mat) out[7] = (float)i;
+    if (h.hits) out[7] = (float)(ob - s->objs);
     return h.hits;
 }
 
@@ -942,6 +975,8 @@ float orc_math_logf(float x, int mode) { return mode == ORC_MATH_DET ? rt_logf(x
 float orc_math_cosf(float x, int mode) { return m_cos(x, mode); }
 float orc_math_sinf(float x, int mode) { return m_sin(x, mode); }
 float orc_math_tanf(float x, int mode) { return m_tan(x, mode); }
+double orc_math_asin(double x, int mode) { return mode == ORC_MATH_DET ? rt_asin(x) : asin(x); }
+double orc_math_acos(double x, int mode) { return mode == ORC_MATH_DET ? rt_acos(x) : acos(x); }
 
 void orc_to_rgba8(const float *rgb, int W, int H, uint8_t *out)
 {   /* parse_pixel_colours src/main.cu:343-371: int(px*255), clamp 0..255, alpha 255 */

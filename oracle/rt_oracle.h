@@ -51,6 +51,8 @@ void orc_material_standard(orc_material *m, int tex_type, const float colour[3],
 void orc_material_checkerboard(orc_material *m, const float light[3], const float dark[3], int num_squares, float smoothness);
 void orc_material_emissive(orc_material *m, const float colour[3], float strength);
 void orc_material_refractive(orc_material *m, const float colour[3], float n);
+/* Material::create_standard(Texture::create_image(w, h, rgb), smoothness): rgb stays owned by the caller */
+void orc_material_image(orc_material *m, int w, int h, const float *rgb, float smoothness);
 
 typedef struct {
     uint64_t samples, bounce_iters, hits, rng_draws;
@@ -116,6 +118,8 @@ float orc_math_logf(float x, int math_mode);
 float orc_math_cosf(float x, int math_mode);
 float orc_math_sinf(float x, int math_mode);
 float orc_math_tanf(float x, int math_mode);
+double orc_math_asin(double x, int math_mode);
+double orc_math_acos(double x, int math_mode);
 /* float -> RGBA8 display conversion, reference src/main.cu:343-371 */
 void orc_to_rgba8(const float *rgb, int W, int H, uint8_t *out);
 

@@ -30,7 +30,8 @@ class rt_material(C.Structure):
     _fields_ = [("type", C.c_int32), ("tex_type", C.c_int32), ("colour", C.c_float * 3),
                 ("light", C.c_float * 3), ("dark", C.c_float * 3), ("num_squares", C.c_int32),
                 ("smoothness", C.c_float), ("need_uv", C.c_int32), ("emitted_light", C.c_float * 3),
-                ("refractive_index", C.c_float)]
+                ("refractive_index", C.c_float), ("img_w", C.c_int32), ("img_h", C.c_int32),
+                ("img_rgb", C.POINTER(C.c_float))]
 
 
 class rt_camera(C.Structure):
@@ -62,6 +63,7 @@ class rt_flat_view(C.Structure):
 # every symbol include/rt_amd.h declares (tests/test_abi.py checks the .so exports them all)
 ABI_SYMBOLS = [
     "rt_material_standard", "rt_material_checkerboard", "rt_material_gradient", "rt_material_emissive",
+    "rt_material_refractive", "rt_material_image", "rt_image_texture_load", "rt_image_texture_free",
     "rt_scene_builder_create", "rt_scene_builder_destroy", "rt_scene_builder_error", "rt_scene_add_sphere",
     "rt_scene_add_triangle", "rt_scene_add_triangle_uv", "rt_scene_add_quad", "rt_scene_add_one_way_quad",
     "rt_scene_add_cuboid", "rt_scene_add_mesh", "rt_scene_add_obj_mesh", "rt_scene_builder_num_objects",
@@ -100,7 +102,13 @@ def lib():
     L.rt_material_checkerboard.argtypes = [pm, fp, fp, C.c_int32, C.c_float]
     L.rt_material_gradient.argtypes = [pm, C.c_float]
     L.rt_material_emissive.argtypes = [pm, fp, C.c_float]
-    for n in ("rt_material_standard", "rt_material_checkerboard", "rt_material_gradient", "rt_material_emissive"):
+    L.rt_material_refractive.argtypes = [pm, fp, C.c_float]
+    L.rt_material_image.argtypes = [pm, C.c_int32, C.c_int32, fp, C.c_float]
+    L.rt_image_texture_load.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(fp)]
+    L.rt_image_texture_free.argtypes = [fp]
+    L.rt_image_texture_free.restype = None
+    for n in ("rt_material_standard", "rt_material_checkerboard", "rt_material_gradient", "rt_material_emissive",
+              "rt_material_refractive", "rt_material_image"):
         getattr(L, n).restype = None
     L.rt_scene_builder_create.argtypes = [C.POINTER(vp)]
     L.rt_scene_builder_destroy.argtypes = [vp]
@@ -203,6 +211,23 @@ class Material:
         return Material(m)
 
     @staticmethod
+    def create_refractive(colour, n):
+        m = rt_material()
+        lib().rt_material_refractive(C.byref(m), _fp(colour)[1], C.c_float(n))
+        return Material(m)
+
+    @staticmethod
+    def create_image(rgb, smoothness):
+        """rgb: [height, width, 3] float32 texels (Texture::create_image src/material.cu:42-51);
+        the scene builder copies them when the object is added"""
+        arr, p = _fp(np.asarray(rgb, np.float32))
+        m = rt_material()
+        lib().rt_material_image(C.byref(m), arr.shape[1], arr.shape[0], p, C.c_float(smoothness))
+        mat = Material(m)
+        mat._keep = arr
+        return mat
+
+    @staticmethod
     def from_desc(desc):
         kind = desc[0]
         if kind == "standard":
@@ -214,13 +239,25 @@ class Material:
         if kind == "gradient":
             return Material.create_gradient(desc[1])
         if kind == "refractive":
-            m = rt_material()
-            m.type = MAT_REFRACTIVE
-            m.colour[:] = [float(x) for x in desc[1]]
-            m.refractive_index = float(desc[2])
-            m.smoothness = 1.0
-            return Material(m)
+            return Material.create_refractive(desc[1], desc[2])
+        if kind == "image":
+            return Material.create_image(desc[1], desc[2])
         raise ValueError(kind)
+
+
+def load_image_texture(parsed_textures_path, name):
+    """ImageTexture src/main.cu:40-91: entry `name` of a baked texture file -> [h, w, 3] float32"""
+    w, h = C.c_int32(), C.c_int32()
+    ptr = C.POINTER(C.c_float)()
+    st = lib().rt_image_texture_load(os.fsencode(parsed_textures_path), name.encode(), C.byref(w), C.byref(h), C.byref(ptr))
+    if st == RT_ERR_IO:
+        raise RayTracerError("Could not find file to open.")
+    if st != RT_OK:
+        raise RayTracerError("Image file not found.\n")
+    try:
+        return np.ctypeslib.as_array(ptr, shape=(h.value, w.value, 3)).copy()
+    finally:
+        lib().rt_image_texture_free(ptr)
 
 
 class ObjFileMesh:

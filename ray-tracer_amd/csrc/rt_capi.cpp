@@ -40,6 +40,7 @@ struct rt_scene {
     rt_f4 *d_blob = nullptr;
     rt_object *d_objects = nullptr;
     float *d_tri_uv = nullptr;
+    float *d_tex = nullptr;
     FlatScene flat;          /* host copy (sizes, offsets) */
     int threads = 0;         /* workgroup size chosen for this scene */
     size_t lds_bytes = 0;
@@ -147,6 +148,10 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
         e = hipMalloc((void **)&s->d_tri_uv, s->flat.tri_uv.size() * 4);
         if (e == hipSuccess) e = hipMemcpy(s->d_tri_uv, s->flat.tri_uv.data(), s->flat.tri_uv.size() * 4, hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess && !s->flat.tex_data.empty()) {
+        e = hipMalloc((void **)&s->d_tex, s->flat.tex_data.size() * 4);
+        if (e == hipSuccess) e = hipMemcpy(s->d_tex, s->flat.tex_data.data(), s->flat.tex_data.size() * 4, hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         rt_scene_destroy(s);
         return hip_fail(ctx, e, "uploading scene");
@@ -162,6 +167,7 @@ extern "C" void rt_scene_destroy(rt_scene *s)
     if (s->d_blob) (void)hipFree(s->d_blob);
     if (s->d_objects) (void)hipFree(s->d_objects);
     if (s->d_tri_uv) (void)hipFree(s->d_tri_uv);
+    if (s->d_tex) (void)hipFree(s->d_tex);
     delete s;
 }
 
@@ -235,6 +241,7 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     a.stack_entries = scene->flat.stack_entries;
     a.work_threshold = ctx->work_threshold;
     a.tri_uv = scene->d_tri_uv;
+    a.tex_data = scene->d_tex;
     a.prev = d_prev;
     a.out = d_out;
     a.tile_counter = ctx->tile_counter;

@@ -8,7 +8,7 @@
  *   LDS-staged blob (one coalesced copy per workgroup, 16-byte units):
  *     nodes   64 B  both children's boxes + child references (one LDS round trip per step)
  *     tris    48 B  p0, side1, side2, unit normal            (reference src/objects.cu:175-186)
- *     objlds  48 B  per top-level object: what shading needs for a per-lane object index
+ *     objlds  64 B  per top-level object: what shading needs for a per-lane object index
  *     meshes  32 B  per mesh object: root box, root reference, object index
  *     objtab  48 B  the object list (rt_object) every lane walks in the same order: wave-uniform
  *                   LDS reads (broadcast) instead of vector global loads
@@ -64,11 +64,14 @@ typedef struct { rt_f4 q[4]; } rt_node;
 /* q0 = (p0.x p0.y p0.z s1.x) q1 = (s1.y s1.z s2.x s2.y) q2 = (s2.z n.x n.y n.z) */
 typedef struct { rt_f4 q[3]; } rt_tri;
 
-/* a = (A.rgb, smoothness): A = colour (COLOUR) or light (CHECKERBOARD)
- * b = (B.rgb, packed): B = emitted light (EMISSIVE) or dark (CHECKERBOARD) ; B.x = refractive index (REFRACTIVE)
+/* a = (A.rgb, smoothness): A = colour (COLOUR), light (CHECKERBOARD) or, as raw ints,
+ *     (width, height, first float in tex_data) (IMAGE)
+ * b = (B.rgb, packed): B = emitted light (EMISSIVE) or dark (CHECKERBOARD)
  *     packed bits: [1:0] material type, [3:2] texture type, [4] need_uv, [5] is_sphere, [31:8] num_squares
- * c = sphere (center.xyz, radius) */
-typedef struct { rt_f4 a, b, c; } rt_objlds;
+ * c = sphere (center.xyz, radius)
+ * d = (refractive index, 0, 0, 0) */
+typedef struct { rt_f4 a, b, c, d; } rt_objlds;
+#define RT_OBJLDS_F4 4
 
 #define RT_PACK_MAT(type, tex, need_uv, is_sphere, nsq) \
     ((uint32_t)(type) | ((uint32_t)(tex) << 2) | ((uint32_t)(need_uv) << 4) | ((uint32_t)(is_sphere) << 5) | ((uint32_t)(nsq) << 8))
@@ -106,6 +109,7 @@ typedef struct {
     int32_t stack_entries;         /* per-lane traversal stack depth (LDS) */
     int32_t work_threshold;        /* run traversal steps while at least this many lanes traverse */
     const float *tri_uv;           /* 6 floats per triangle, or NULL */
+    const float *tex_data;         /* IMAGE texture texels (rgb floats), or NULL */
     /* frame buffers */
     const float *prev;             /* full frame or NULL */
     float *out;

@@ -24,6 +24,8 @@
 
 namespace {
 
+std::vector<std::string> split_string(const std::string &str, char split_char);
+
 struct F3 {
     float x, y, z;
 };
@@ -71,14 +73,22 @@ rt_status fail(rt_scene_builder *b, rt_status code, const char *msg)
     return code;
 }
 
+void keep_texels(HostObject &o)
+{   /* Texture::allocate_memory src/material.cu:107-117 copies the texels to the device at
+     * creation; here the builder takes its own copy so the caller's array may go away */
+    if (o.mat.tex_type == RT_TEX_IMAGE && o.mat.type != RT_MAT_EMISSIVE && o.mat.img_rgb)
+        o.texels.assign(o.mat.img_rgb, o.mat.img_rgb + (size_t)o.mat.img_w * (size_t)o.mat.img_h * 3);
+    o.mat.img_rgb = nullptr;
+}
+
 rt_status check_material(rt_scene_builder *b, const rt_material *m, bool is_sphere)
 {
     if (!b || !m) return fail(b, RT_ERR_INVALID, "null argument");
-    if (m->type == RT_MAT_REFRACTIVE) return fail(b, RT_ERR_UNSUPPORTED, "REFRACTIVE materials are not supported yet");
-    if (m->type != RT_MAT_STANDARD && m->type != RT_MAT_EMISSIVE) return fail(b, RT_ERR_INVALID, "unknown material type");
-    if (m->tex_type == RT_TEX_IMAGE) return fail(b, RT_ERR_UNSUPPORTED, "IMAGE textures are not supported yet");
+    (void)is_sphere;
+    if (m->type != RT_MAT_STANDARD && m->type != RT_MAT_EMISSIVE && m->type != RT_MAT_REFRACTIVE) return fail(b, RT_ERR_INVALID, "unknown material type");
     if (m->tex_type < 0 || m->tex_type > RT_TEX_IMAGE) return fail(b, RT_ERR_INVALID, "unknown texture type");
-    if (is_sphere && m->need_uv && m->type != RT_MAT_EMISSIVE) return fail(b, RT_ERR_UNSUPPORTED, "textured spheres are not supported yet");
+    if (m->tex_type == RT_TEX_IMAGE && m->type != RT_MAT_EMISSIVE &&
+        (m->img_w <= 0 || m->img_h <= 0 || !m->img_rgb || (int64_t)m->img_w * m->img_h > (1 << 26))) return fail(b, RT_ERR_INVALID, "IMAGE texture without data");
     if (m->tex_type == RT_TEX_CHECKERBOARD && (m->num_squares < 0 || m->num_squares >= (1 << 24))) return fail(b, RT_ERR_INVALID, "num_squares out of range");
     return RT_OK;
 }
@@ -191,6 +201,7 @@ rt_status add_mesh_tris(rt_scene_builder *b, const std::vector<HostTri> &tris, c
     o.nodes = std::move(bb.nodes);
     o.tris.reserve(tris.size());
     for (int i : bb.order) o.tris.push_back(tris[i]);
+    keep_texels(o);
     b->objs.push_back(std::move(o));
     return RT_OK;
 }
@@ -274,6 +285,66 @@ extern "C" void rt_material_gradient(rt_material *m, float smoothness)
     m->need_uv = 1;
 }
 
+extern "C" void rt_material_refractive(rt_material *m, const float colour[3], float n)
+{
+    std::memset(m, 0, sizeof *m);
+    m->type = RT_MAT_REFRACTIVE;
+    m->tex_type = RT_TEX_COLOUR;
+    std::memcpy(m->colour, colour, 12);
+    m->refractive_index = n;
+    m->need_uv = 0;
+    m->smoothness = 1;                 /* src/material.cu:182 */
+}
+
+extern "C" void rt_material_image(rt_material *m, int32_t width, int32_t height, const float *rgb, float smoothness)
+{
+    std::memset(m, 0, sizeof *m);
+    m->type = RT_MAT_STANDARD;
+    m->tex_type = RT_TEX_IMAGE;
+    m->smoothness = smoothness;
+    m->need_uv = 1;
+    m->img_w = width;
+    m->img_h = height;
+    m->img_rgb = rgb;
+}
+
+extern "C" rt_status rt_image_texture_load(const char *path, const char *name, int32_t *width, int32_t *height, float **rgb)
+{   /* ImageTexture::parse_file / parse_rgb_values src/main.cu:58-90 */
+    if (!path || !name || !width || !height || !rgb) return RT_ERR_INVALID;
+    *rgb = nullptr;
+    std::ifstream file(path);
+    if (!file) return RT_ERR_IO;
+    std::vector<std::string> lines;
+    std::string line;
+    while (std::getline(file, line)) lines.push_back(line);
+    for (size_t i = 0; i + 3 < lines.size(); i++) {
+        if (lines[i] != name) continue;
+        try {
+            *width = std::stoi(lines[i + 1]);
+            *height = std::stoi(lines[i + 2]);
+            std::vector<std::string> tok = split_string(lines[i + 3], ' ');
+            std::vector<float> v;
+            /* "the last character will just be ''": loop to the last but one token, in threes */
+            for (size_t k = 0; k + 1 < tok.size() && k + 2 < tok.size(); k += 3) {
+                v.push_back(std::stof(tok[k]));
+                v.push_back(std::stof(tok[k + 1]));
+                v.push_back(std::stof(tok[k + 2]));
+            }
+            if (*width <= 0 || *height <= 0 || v.size() < (size_t)*width * (size_t)*height * 3) return RT_ERR_INVALID;
+            float *out = (float *)std::malloc(v.size() * sizeof(float));
+            if (!out) return RT_ERR_NOMEM;
+            std::memcpy(out, v.data(), v.size() * sizeof(float));
+            *rgb = out;
+            return RT_OK;
+        } catch (const std::exception &) {
+            return RT_ERR_INVALID;
+        }
+    }
+    return RT_ERR_INVALID;             /* "Image file not found." */
+}
+
+extern "C" void rt_image_texture_free(float *rgb) { std::free(rgb); }
+
 extern "C" void rt_material_emissive(rt_material *m, const float colour[3], float strength)
 {
     std::memset(m, 0, sizeof *m);
@@ -302,6 +373,7 @@ extern "C" rt_status rt_scene_add_sphere(rt_scene_builder *b, const float center
     o.type = RT_OBJ_SPHERE;
     o.mat = *m;
     o.v[0] = center[0]; o.v[1] = center[1]; o.v[2] = center[2]; o.v[3] = radius;
+    keep_texels(o);
     b->objs.push_back(std::move(o));
     return RT_OK;
 }
@@ -313,6 +385,7 @@ extern "C" rt_status rt_scene_add_triangle(rt_scene_builder *b, const float p1[3
     o.type = RT_OBJ_TRIANGLE;
     o.mat = *m;
     o.tris.push_back(make_tri(f3(p1), f3(p2), f3(p3)));
+    keep_texels(o);
     b->objs.push_back(std::move(o));
     return RT_OK;
 }
@@ -326,6 +399,7 @@ extern "C" rt_status rt_scene_add_triangle_uv(rt_scene_builder *b, const float p
     HostTri t = make_tri(f3(p), f3(p + 3), f3(p + 6));
     std::memcpy(t.uv, uv, 24);
     o.tris.push_back(t);
+    keep_texels(o);
     b->objs.push_back(std::move(o));
     return RT_OK;
 }
@@ -337,6 +411,7 @@ extern "C" rt_status rt_scene_add_quad(rt_scene_builder *b, const float p1[3], c
     o.type = RT_OBJ_QUAD;
     o.mat = *m;
     make_quad(o.tris, f3(p1), f3(p2), f3(p3), f3(p4));
+    keep_texels(o);
     b->objs.push_back(std::move(o));
     return RT_OK;
 }
@@ -351,6 +426,7 @@ extern "C" rt_status rt_scene_add_one_way_quad(rt_scene_builder *b, const float 
     /* OneWayQuad::get_normal_vec src/objects.cu:285-289 */
     float multiplier = (float)(1 - 2 * (invert_normal != 0));
     o.v[0] = o.tris[0].n[0] * multiplier; o.v[1] = o.tris[0].n[1] * multiplier; o.v[2] = o.tris[0].n[2] * multiplier;
+    keep_texels(o);
     b->objs.push_back(std::move(o));
     return RT_OK;
 }
@@ -371,6 +447,7 @@ extern "C" rt_status rt_scene_add_cuboid(rt_scene_builder *b, const float tl_nea
     make_quad(o.tris, tr_near, br_near, br_far, tr_far);
     make_quad(o.tris, bl_near, br_near, br_far, bl_far);
     make_quad(o.tris, tl_near, tr_near, tr_far, tl_far);
+    keep_texels(o);
     b->objs.push_back(std::move(o));
     return RT_OK;
 }
@@ -608,7 +685,7 @@ std::string rt_flatten(const rt_scene_builder &b, FlatScene &out)
     out.off_nodes = 0;
     out.off_tris = (int)(n_nodes * 4);
     out.off_objlds = out.off_tris + (int)(n_tris * 3);
-    out.off_meshes = out.off_objlds + (int)(b.objs.size() * 3);
+    out.off_meshes = out.off_objlds + (int)(b.objs.size() * RT_OBJLDS_F4);
     out.num_meshes = (int)n_meshes;
     out.off_objtab = out.off_meshes + (int)(n_meshes * 2);
     static_assert(sizeof(rt_object) == 48, "rt_object is three 16-byte units");
@@ -663,13 +740,18 @@ std::string rt_flatten(const rt_scene_builder &b, FlatScene &out)
         }
         /* per-object shading record */
         const rt_material &m = o.mat;
-        rt_f4 *rec = &out.blob[(size_t)out.off_objlds + oi * 3];
+        rt_f4 *rec = &out.blob[(size_t)out.off_objlds + oi * RT_OBJLDS_F4];
         const float *A = (m.tex_type == RT_TEX_CHECKERBOARD) ? m.light : m.colour;
         const float *B = (m.type == RT_MAT_EMISSIVE) ? m.emitted_light : m.dark;
         uint32_t packed = RT_PACK_MAT(m.type, m.tex_type, m.need_uv ? 1 : 0, o.type == RT_OBJ_SPHERE ? 1 : 0, m.tex_type == RT_TEX_CHECKERBOARD ? m.num_squares : 0);
         rec[0] = rt_f4{A[0], A[1], A[2], m.smoothness};
+        if (m.tex_type == RT_TEX_IMAGE && m.type != RT_MAT_EMISSIVE) {
+            rec[0] = rt_f4{rt_u2f((uint32_t)m.img_w), rt_u2f((uint32_t)m.img_h), rt_u2f((uint32_t)out.tex_data.size()), m.smoothness};
+            out.tex_data.insert(out.tex_data.end(), o.texels.begin(), o.texels.end());
+        }
         rec[1] = rt_f4{B[0], B[1], B[2], rt_u2f(packed)};
         rec[2] = rt_f4{o.v[0], o.v[1], o.v[2], o.v[3]};
+        rec[3] = rt_f4{m.refractive_index, 0.0f, 0.0f, 0.0f};
         out.objects.push_back(ro);
         std::memcpy(&out.blob[(size_t)out.off_objtab + oi * 3], &ro, sizeof ro);
         node_base += o.nodes.size();

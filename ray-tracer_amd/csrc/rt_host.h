@@ -22,6 +22,7 @@ struct HostObject {
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};   /* see rt_object */
     std::vector<HostTri> tris;           /* top-level shapes: 1 / 2 / 12; meshes: leaf order */
     std::vector<rt_node> nodes;          /* meshes: child refs relative to this object */
+    std::vector<float> texels;           /* IMAGE texture: a copy of the caller's rgb data */
     uint32_t root_ref = RT_REF_EMPTY_LEAF;
     int stack_need = 0;
 };
@@ -48,6 +49,7 @@ struct FlatScene {
     int stack_entries = 1;                       /* per-lane traversal stack depth this scene needs */
     std::vector<rt_object> objects;
     std::vector<float> tri_uv;                   /* empty unless some material needs UVs */
+    std::vector<float> tex_data;                 /* IMAGE texels of all objects, back to back */
     int num_tris = 0, num_nodes = 0;
     bool has_mesh = false;
 };

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
     uint32_t rng = 0;
     V3 colour = v3(0.f, 0.f, 0.f), fin = colour, thr = colour, o = colour, d = colour, inv = colour, primary = colour;
     int sample = 0, bounce = 0, px = 0, py = 0;
+    float cur_n = 1.0f;                  /* Ray::current_refractive_index src/ray.cu:56,144 */
     float best_t = RT_INF_F;
     int best_obj = -1, best_prim = -1, next_mesh = 0;
     /* ---- per-lane traversal state (registers + LDS stack) ---- */
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                 end_sample = true;
             } else {
                 RT_STAT(ST_SHADE_HIT);
-                const v4f ma = L.objs[3 * best_obj], mb = L.objs[3 * best_obj + 1];
+                const v4f ma = L.objs[RT_OBJLDS_F4 * best_obj], mb = L.objs[RT_OBJLDS_F4 * best_obj + 1];
                 const uint32_t packed = __float_as_uint(mb.w);
                 const int mtype = (int)(packed & 3u);
                 /* hit point and normal: Ray::get_pos src/ray.cu:63-65; Sphere :66; Triangle :158 */
@@ -209,8 +210,19 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                 V3 N;
                 float tex_u = 0.f, tex_v = 0.f;
                 if (packed & 32u) {
-                    const v4f sc = L.objs[3 * best_obj + 2];
+                    const v4f sc = L.objs[RT_OBJLDS_F4 * best_obj + 2];
                     N = normalised(P - v3(sc.x, sc.y, sc.z));
+                    if (packed & 16u) {
+                        /* Sphere::assign_texture_coords src/objects.cu:82-97 (latitude / longitude) */
+                        const float PI = 3.141592653589793f;
+                        const float theta = rt_asinf((P.y - sc.y) / sc.w);
+                        const float phi = rt_acosf((P.x - sc.x) / sc.w);
+                        tex_u = (theta + PI / 2) / PI;
+                        const float v_ratio = (1 - phi / PI) / 2;
+                        const int behind = P.z > sc.z ? 1 : 0;
+                        const int mult = 1 - 2 * behind;
+                        tex_v = (float)(1 * behind) + (float)mult * v_ratio;
+                    }
                 } else {
                     const v4f q2 = L.tris[3 * best_prim + 2];
                     V3 n = v3(q2.y, q2.z, q2.w);
@@ -225,19 +237,52 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                         tex_v = uv[1] * w + uv[3] * u + uv[5] * v;
                     }
                 }
-                /* Ray::reflect src/ray.cu:67-75 with diffuse_reflect :157-170,
-                 * true_lambertian_reflect :172-178, perfect_reflect :180-186, lerp :32-34 */
-                float gx = normal_num(rng);
-                float gy = normal_num(rng);
-                float gz = normal_num(rng);
-                V3 rv = v3(gx, gy, gz);
-                if (dot(rv, N) < 0.0f) rv = neg(rv);
-                rv = normalised(rv);
-                V3 diffuse_dir = normalised(N + rv);
-                float dn = dot(d, N);
-                V3 specular_dir = normalised(d - (N * 2.0f) * dn);
+                /* update_ray src/raytracer.cu:49-64: REFRACTIVE goes through Ray::refract
+                 * (src/ray.cu:77-128, Snell + Schlick + total internal reflection), which falls
+                 * back to reflect(); everything else reflects */
+                bool do_reflect = true;
+                V3 refr_dir = v3(0.f, 0.f, 0.f);
+                if (mtype == RT_DEV_MAT_REFRACTIVE) {
+                    const float mat_n = L.objs[RT_OBJLDS_F4 * best_obj + 3].x;
+                    float n1, n2;
+                    V3 rn;
+                    if (dot(N, d) > 0.0f) { n1 = mat_n; n2 = cur_n; rn = N; }        /* leaving the object */
+                    else                  { n1 = cur_n; n2 = mat_n; rn = neg(N); }   /* entering */
+                    cur_n = n2;
+                    /* min(float, double) is CUDA's double overload; acos / asin of doubles */
+                    const float theta1 = (float)rt_acos(fmin((double)dot(d, rn), 1.0));
+                    const float theta2 = (float)rt_asin(fmin((double)(n1 * rt_sinf(theta1) / n2), 1.0));
+                    const float critical_angle = rt_asinf(n2 / n1);
+                    /* get_reflection_coeff :188-196: pow(float, int) is the double pow */
+                    const float sqrt_r0 = (n1 - n2) / (n1 + n2);
+                    const float r0 = sqrt_r0 * sqrt_r0;
+                    const float cos_theta = rt_cosf(theta1);
+                    const float reflection_coeff = (float)((double)r0 + (double)(1.0f - r0) * rt_pow5((double)(1.0f - cos_theta)));
+                    do_reflect = theta1 > critical_angle;
+                    if (!do_reflect) do_reflect = reflection_coeff > rt_u01(rt_pcg_next(&rng));   /* `||` short-circuits */
+                    if (!do_reflect) {
+                        V3 perp = v3(0.f, 0.f, 0.f);
+                        if (theta1 != 0.0f) perp = (d - rn * rt_cosf(theta1)) / rt_sinf(theta1);
+                        refr_dir = normalised(rn * rt_cosf(theta2) + perp * rt_sinf(theta2));
+                    }
+                }
+                if (do_reflect) {
+                    /* Ray::reflect src/ray.cu:67-75 with diffuse_reflect :157-170,
+                     * true_lambertian_reflect :172-178, perfect_reflect :180-186, lerp :32-34 */
+                    float gx = normal_num(rng);
+                    float gy = normal_num(rng);
+                    float gz = normal_num(rng);
+                    V3 rv = v3(gx, gy, gz);
+                    if (dot(rv, N) < 0.0f) rv = neg(rv);
+                    rv = normalised(rv);
+                    V3 diffuse_dir = normalised(N + rv);
+                    float dn = dot(d, N);
+                    V3 specular_dir = normalised(d - (N * 2.0f) * dn);
+                    d = normalised(diffuse_dir + (specular_dir - diffuse_dir) * ma.w);
+                } else {
+                    d = refr_dir;
+                }
                 o = P;
-                d = normalised(diffuse_dir + (specular_dir - diffuse_dir) * ma.w);
 
                 /* src/raytracer.cu:86-90 */
                 if (mtype == RT_DEV_MAT_EMISSIVE) {
@@ -249,6 +294,14 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                         tc = v3(ma.x, ma.y, ma.z);
                     } else if (tex == 1) {
                         tc = v3(tex_u, tex_v, 0.f);                              /* gradient src/material.cu:80-82 */
+                    } else if (tex == 3) {
+                        /* image src/material.cu:119-124: nearest texel; an out-of-range index is clamped */
+                        const int iw = (int)__float_as_uint(ma.x), ih = (int)__float_as_uint(ma.y);
+                        const int uc = (int)((float)(iw - 1) * tex_u), vc = (int)((float)(ih - 1) * tex_v);
+                        int idx = vc * iw + uc;
+                        idx = idx < 0 ? 0 : (idx > iw * ih - 1 ? iw * ih - 1 : idx);
+                        const float *tx = a.tex_data + (size_t)__float_as_uint(ma.z) + 3 * (size_t)idx;
+                        tc = v3(tx[0], tx[1], tx[2]);
                     } else {
                         const int nsq = (int)(packed >> 8);                      /* checkerboard :90-99 */
                         int uc = (int)(tex_u * (float)nsq), vc = (int)(tex_v * (float)nsq);
@@ -265,7 +318,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                 colour = colour + fin;
                 sample++;
                 fin = v3(0.f, 0.f, 0.f); thr = v3(1.f, 1.f, 1.f);
-                o = cam_pos; d = primary; bounce = 0;
+                o = cam_pos; d = primary; bounce = 0; cur_n = 1.0f;
                 if (sample >= spp) {
                     /* src/raytracer.cu:107-112 and :133-135 */
                     const int array_index = (py * W + px) * 3;
@@ -332,7 +385,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                             colour = v3(0.f, 0.f, 0.f);
                             fin = v3(0.f, 0.f, 0.f); thr = v3(1.f, 1.f, 1.f);
                             o = cam_pos; d = primary;
-                            bounce = 0;
+                            bounce = 0; cur_n = 1.0f;
                             /* a zero bounce limit traces nothing: every sample is (0,0,0) */
                             sample = limit > 0 ? 0 : spp;
                             if (sample >= spp) {

@@ -144,4 +144,79 @@ RT_HD float rt_cosf(float x)
 
 RT_HD float rt_tanf(float x) { return rt_sinf(x) / rt_cosf(x); }
 
+
+/* ---- arcsine / arccosine / fifth power (binary64) -------------------------------------------
+ * Needed by Ray::refract (src/ray.cu:101-102,123: acos/asin of double arguments, pow(x, 5))
+ * and by the sphere texture coordinates (src/objects.cu:84-85: float asin/acos, evaluated here
+ * through the binary64 routines and rounded once).  asin(x) on |x| <= 1/2 is its Maclaurin
+ * series through x^55 (terms fall by > 4x each; the remainder is below 2e-18); for 1/2 < |x| <= 1
+ * asin(x) = pi/2 - 2 asin(sqrt((1-|x|)/2)).  Only IEEE + - * / sqrt. */
+RT_HD double rt__asin_series(double x)
+{
+    /* Horner, highest coefficient first; coefficients (2n)! / (4^n n!^2 (2n+1)) */
+    const double z = x * x;
+    double p = 0.0019650336162772837;
+    p = p * z + 0.0020776610325181676;
+    p = p * z + 0.0022014739737101384;
+    p = p * z + 0.002338091892111975;
+    p = p * z + 0.0024894486782468836;
+    p = p * z + 0.0026578706382072901;
+    p = p * z + 0.0028461784011089421;
+    p = p * z + 0.0030578216492580306;
+    p = p * z + 0.0032970595034734849;
+    p = p * z + 0.0035692053938259347;
+    p = p * z + 0.0038809645588376691;
+    p = p * z + 0.0042409070936793632;
+    p = p * z + 0.0046601434869150962;
+    p = p * z + 0.0051533096823199046;
+    p = p * z + 0.0057400376708419236;
+    p = p * z + 0.0064472103118896487;
+    p = p * z + 0.0073125258735988454;
+    p = p * z + 0.0083903358096168151;
+    p = p * z + 0.0097616095291940784;
+    p = p * z + 0.011551800896139705;
+    p = p * z + 0.013964843750000001;
+    p = p * z + 0.017352764423076924;
+    p = p * z + 0.022372159090909092;
+    p = p * z + 0.030381944444444444;
+    p = p * z + 0.044642857142857144;
+    p = p * z + 0.074999999999999997;
+    p = p * z + 0.16666666666666666;
+    p = p * z + 1.0;
+    return x * p;
+}
+
+#if defined(__HIPCC__)
+#define RT_SQRT_F64(x) __builtin_sqrt(x)
+#else
+#define RT_SQRT_F64(x) __builtin_sqrt(x)
+#endif
+
+RT_HD double rt_asin(double x)
+{
+    const double PIO2_HI = 1.5707963267948966, PIO2_LO = 6.123233995736766e-17;
+    const double ax = x < 0 ? -x : x;
+    if (!(ax <= 1.0)) return (x - x) / (x - x);                 /* |x| > 1 or NaN -> NaN */
+    if (ax <= 0.5) return rt__asin_series(x);
+    const double s = RT_SQRT_F64((1.0 - ax) * 0.5);
+    const double r = (PIO2_HI - 2.0 * rt__asin_series(s)) + PIO2_LO;
+    return x < 0 ? -r : r;
+}
+
+RT_HD double rt_acos(double x)
+{
+    const double PIO2_HI = 1.5707963267948966, PIO2_LO = 6.123233995736766e-17;
+    const double ax = x < 0 ? -x : x;
+    if (!(ax <= 1.0)) return (x - x) / (x - x);
+    if (ax <= 0.5) return (PIO2_HI - rt__asin_series(x)) + PIO2_LO;
+    const double s = RT_SQRT_F64((1.0 - ax) * 0.5);
+    const double t = 2.0 * rt__asin_series(s);
+    return x > 0 ? t : (2.0 * PIO2_HI - t) + 2.0 * PIO2_LO;
+}
+
+RT_HD float rt_asinf(float x) { return (float)rt_asin((double)x); }
+RT_HD float rt_acosf(float x) { return (float)rt_acos((double)x); }
+/* pow(x, 5) as the reference's Schlick term uses it (src/ray.cu:195), in binary64 */
+RT_HD double rt_pow5(double x) { const double x2 = x * x; return (x2 * x2) * x; }
+
 #endif /* RT_MATH_H */

@@ -92,9 +92,7 @@ public:
     static Material create_refractive(Texture mat_tex, float n)
     {
         Material m;
-        rt_material_standard(&m.c, mat_tex.colour.data(), 1.0f);   /* smoothness = 1, src/material.cu:182 */
-        m.c.type = RT_MAT_REFRACTIVE;
-        m.c.refractive_index = n;
+        rt_material_refractive(&m.c, mat_tex.colour.data(), n);
         return m;
     }
 };
@@ -134,14 +132,15 @@ public:
     {
         if (rt_scene_builder_create(&b_) != RT_OK) throw std::bad_alloc();
     }
-    /* SceneObjects(int test_scene) src/main.cu:100-122: scenes 0 and 1 (2 needs an image texture,
-     * 3 and 4 need the refractive material; both are later rows of SURVEY.md §8(f)) */
+    /* SceneObjects(int test_scene) src/main.cu:100-122: scenes 0, 1 and 3 */
     SceneObjects(int test_scene, const std::string &models_dir) : SceneObjects()
     {
         switch (test_scene) {
             case 0: monkey_test_scene(models_dir); break;
             case 1: reflection_test_scene(); break;
-            case 2: case 3: case 4: throw std::logic_error("this test scene needs a material that is not supported yet");
+            case 3: refract_test_scene(); break;
+            case 2: throw std::runtime_error("Could not find file to open.");       /* textures/parsed_textures.txt is not shipped upstream */
+            case 4: throw std::logic_error("scene 4 is unseeded in the reference; use ray-tracer_amd.scenes.reference_scene4");
             default: throw std::domain_error("Test scene must be number between 0 and 3 (inclusive).\n");   /* :118 */
         }
     }
@@ -214,6 +213,11 @@ private:
         m.translate(0.1f, -0.1f, 1.6f);
         create_mesh(m, Material::create_standard(Texture::create_const_colour(Vec3(1, 1, 1)), 0));
         create_sphere(Vec3(-0.25f, -0.25f, 1.95f), 0.25f, Material::create_standard(Texture::create_const_colour(Vec3(0.8f, 0.8f, 0.8f)), 1));
+    }
+    void refract_test_scene()
+    {   /* src/main.cu:206-213 */
+        create_cornell_box(Vec3(-0.5f, 0.5f, 1.2f), 1, 1, 1, 0.5f);
+        create_sphere(Vec3(0, -0.1f, 1.7f), 0.3f, Material::create_refractive(Texture::create_const_colour(Vec3(1, 1, 1)), 1.5f));
     }
     void reflection_test_scene()
     {   /* src/main.cu:172-187 */

@@ -15,7 +15,7 @@ distance ties, reference src/raytracer.cu:36):
 
 and a material is ('standard', colour, smoothness) | ('emissive', colour, strength) |
 ('checkerboard', light, dark, num_squares, smoothness) | ('gradient', smoothness) |
-('refractive', colour, n) — the arguments of the reference's Material::create_* /
+('refractive', colour, n) | ('image', rgb[h,w,3], smoothness) — the arguments of the reference's Material::create_* /
 Texture::create_* factories (src/material.cu:21-51, :157-185).
 """
 
@@ -145,5 +145,63 @@ def reference_scene1():
     return objs, NO_SKY
 
 
+def reference_scene3():
+    """reference src/main.cu:206-213 (refract_test_scene)."""
+    objs = cornell_box()
+    objs.append(("sphere", (0, -0.1, 1.7), 0.3, ("refractive", (1, 1, 1), 1.5)))
+    return objs, NO_SKY
+
+
+def procedural_image(width=64, height=32, seed=1):
+    """A stand-in for the reference's earth.png (git-ignored upstream): smooth
+    coloured bands + noise, float32 [height, width, 3] in [0, 1), quantised to n/256 like
+    textures/parse_textures.py does."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:height, 0:width]
+    img = np.stack([0.5 + 0.5 * np.sin(x / 5.0), 0.5 + 0.5 * np.cos(y / 3.0), (x + y) % 16 / 16.0], axis=2)
+    img = np.clip(img * 0.85 + rng.uniform(0, 0.15, img.shape), 0, 0.999)
+    return (np.floor(img * 256) / 256).astype(np.float32)
+
+
+def reference_scene2(image=None):
+    """reference src/main.cu:189-204 (texture_test_scene) with a procedural image in place of
+    the absent earth.png."""
+    objs = cornell_box()
+    objs.append(("sphere", (0, 0, 1.7), 0.25, ("image", procedural_image() if image is None else image, 0)))
+    objs.append(("triangle_uv", [(0.1, 0, 1.7), (0.6, 0.5, 1.9), (0.8, 0.4, 2)], [(0, 0), (0, 1), (1, 1)],
+                 ("checkerboard", (1, 1, 1), (0, 0, 0), 4, 0)))
+    return objs, NO_SKY
+
+
+def reference_scene4(seed=2024, num_spheres=100):
+    """reference src/main.cu:215-250 (rand_sphere_test_scene) with a SEEDED host generator (the
+    reference draws from std::random_device, so its scene differs on every run).  30 % standard,
+    30 % refractive, 40 % default-constructed Material — undefined in the reference (SURVEY.md
+    App. A.9), defined here as a black diffuse STANDARD material."""
+    rng = np.random.default_rng(seed)
+
+    def host_rng(lo, hi):
+        return float(np.float32(lo + np.float32(rng.random()) * (hi - lo)))
+
+    floor_y, floor_w, floor_d = -1.0, 10.0, 10.0
+    objs = []
+    for _ in range(num_spheres):
+        colour = (host_rng(0, 1), host_rng(0, 1), host_rng(0, 1))
+        mat_num = host_rng(0, 1)
+        if mat_num < 0.3:
+            mat = std(colour, host_rng(0, 1))
+        elif mat_num < 0.6:
+            mat = ("refractive", colour, host_rng(0.5, 2))
+        else:
+            mat = std((0, 0, 0), 0)
+        radius = host_rng(0.1, 0.5)
+        center = (host_rng(-floor_w / 2, floor_w / 2), float(np.float32(floor_y) + np.float32(radius)), host_rng(0, floor_d))
+        objs.append(("sphere", center, radius, mat))
+    objs.append(("quad", (-floor_w / 2, floor_y, 0), (floor_w / 2, floor_y, 0), (floor_w / 2, floor_y, floor_d), (-floor_w / 2, floor_y, floor_d),
+                 ("checkerboard", (0.7, 0.7, 0.7), (0.4, 0.4, 0.4), 10, 0)))
+    return objs, SKY_COLOUR
+
+
 CONFIG_SCENES = {"three_sphere": three_sphere, "cube": cube, "monkey": monkey,
-                 "reference_scene0": reference_scene0, "reference_scene1": reference_scene1}
+                 "reference_scene0": reference_scene0, "reference_scene1": reference_scene1,
+                 "reference_scene2": reference_scene2, "reference_scene3": reference_scene3, "reference_scene4": reference_scene4}

@@ -161,7 +161,7 @@ class FlatScene:
                 best_t, best_obj, best_prim = t, i, prim
         if best_obj < 0:
             return False, INF, -1, None
-        rec = self.objlds[3 * best_obj:3 * best_obj + 3].reshape(12)
+        rec = self.objlds[4 * best_obj:4 * best_obj + 4].reshape(16)     # rt_objlds: a, b, c, d
         packed = int(rec[7:8].view(np.uint32)[0])
         P = (d * best_t + o).astype(f32)
         if packed & 32:

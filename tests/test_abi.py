@@ -4,6 +4,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 from conftest import ROOT
@@ -28,7 +30,7 @@ def test_library_exports_every_declared_symbol(rt):
 
 def test_struct_layouts(rt):
     # the ctypes mirrors must match the header's PODs (4-byte fields, no padding)
-    assert ctypes.sizeof(rt.rt_material) == 4 * (2 + 3 + 3 + 3 + 1 + 1 + 1 + 3 + 1)
+    assert ctypes.sizeof(rt.rt_material) == 4 * (2 + 3 + 3 + 3 + 1 + 1 + 1 + 3 + 1) + 8 + 8      # ... + img_w, img_h + pointer
     assert ctypes.sizeof(rt.rt_camera) == 4 * 14
     assert ctypes.sizeof(rt.rt_render_settings) == 4 * 6
     assert ctypes.sizeof(rt.rt_tile_spec) == 16
@@ -42,6 +44,11 @@ def test_material_factories(rt):
     assert list(e.emitted_light) == [6.0, 3.0, 1.5] and e.smoothness == 0.0 and e.need_uv == 0 and e.type == rt.MAT_EMISSIVE
     c = rt.Material.create_checkerboard((1, 1, 1), (0, 0, 0), 8, 0).c
     assert (c.tex_type, c.need_uv, c.num_squares) == (rt.TEX_CHECKERBOARD, 1, 8)
+    r = rt.Material.create_refractive((1, 1, 1), 1.5).c
+    # src/material.cu:175-185: smoothness forced to 1
+    assert (r.type, r.smoothness, r.need_uv) == (rt.MAT_REFRACTIVE, 1.0, 0) and abs(r.refractive_index - 1.5) < 1e-7
+    i = rt.Material.create_image(np.zeros((4, 6, 3), np.float32), 0.5).c
+    assert (i.tex_type, i.need_uv, i.img_w, i.img_h) == (rt.TEX_IMAGE, 1, 6, 4)
 
 
 def test_no_gpu_means_failure_not_fallback(rt):

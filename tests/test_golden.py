@@ -9,7 +9,7 @@ import pytest
 
 from conftest import GOLDEN
 
-SCENES = ["three_sphere", "cube", "monkey", "reference_scene0", "reference_scene1"]
+SCENES = ["three_sphere", "cube", "monkey", "reference_scene0", "reference_scene1", "reference_scene2", "reference_scene3", "reference_scene4"]
 
 
 @pytest.mark.parametrize("name", SCENES)

@@ -36,6 +36,10 @@ CASES = [
     ("monkey", 57, 33, 3, 2, False),
     ("reference_scene0", 250, 200, 8, 5, True),    # the reference's own default scene, its aspect ratio
     ("reference_scene1", 250, 200, 8, 5, True),
+    ("reference_scene2", 250, 200, 8, 5, True),    # image-textured sphere (UVs via asin/acos) + checkerboard triangle
+    ("reference_scene3", 250, 200, 8, 5, True),    # refractive sphere: Snell, Schlick, total internal reflection
+    ("reference_scene3", 128, 96, 4, 12, False),
+    ("reference_scene4", 320, 180, 6, 8, True),    # 100 spheres (standard / refractive / default) on a checkerboard quad
 ]
 
 
@@ -271,3 +275,25 @@ def test_bench_two_ranks_on_one_gpu():
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["unit"] == "Msamples/s" and j["value"] > 0
     assert j["gathered_equals_single_launch"] is True
     assert "roofline" in j and j["roofline"]["bound"] == "hbm"
+
+
+def test_textured_and_refractive_primitives(rt, orc, ctx, models_dir):
+    """every texture kind on spheres and on triangle-based shapes, refractive quads / cuboid /
+    mesh (normals flipped against the ray), nested refractive spheres"""
+    img = rt.scenes.procedural_image(40, 20, seed=5)
+    objs = [
+        ("sphere", (-0.7, 0.1, 1.8), 0.3, ("checkerboard", (1, 1, 1), (0.1, 0.1, 0.4), 6, 0.2)),
+        ("sphere", (0.0, 0.1, 1.8), 0.3, ("gradient", 0)),
+        ("sphere", (0.7, 0.1, 1.8), 0.3, ("image", img, 0.1)),
+        ("quad", (-1.5, -0.4, 1), (1.5, -0.4, 1), (1.5, -0.4, 4), (-1.5, -0.4, 4), ("image", img, 0)),
+        ("sphere", (0.0, 0.1, 1.2), 0.2, ("refractive", (0.9, 1.0, 0.9), 1.5)),
+        ("sphere", (0.0, 0.1, 1.2), 0.1, ("refractive", (1.0, 0.8, 0.8), 1.2)),          # nested
+        ("cuboid", (0.35, 0.0, 1.1), 0.25, 0.3, 0.25, ("refractive", (1, 1, 1), 1.3)),
+        ("obj", "cube.obj", [("enlarge", 0.12), ("rotate", 0.5, 0.3, 0.1), ("translate", -0.5, -0.1, 1.2)], ("refractive", (0.8, 0.9, 1.0), 2.0)),
+        ("quad", (-1.5, 1.0, 3.9), (1.5, 1.0, 3.9), (1.5, -0.4, 3.9), (-1.5, -0.4, 3.9), ("emissive", (1, 1, 0.9), 2)),
+    ]
+    sky = (0.8, 1.0, 1.0)
+    got = hip_render(rt, ctx, objs, 200, 120, 8, 10, sky)
+    want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(200, 120).floats(), 200, 120, 8, 10, sky)
+    assert eq(got, want)
+    assert np.isfinite(got).all()

@@ -80,12 +80,27 @@ def test_error_behaviour(rt, tmp_path):
     so = rt.SceneObjects()
     with pytest.raises(rt.UnsupportedMeshError):
         so.create_mesh(m, rt.Material.create_standard((1, 1, 1), 0))
-    # not built yet: rejected loudly, never silently mis-rendered
-    with pytest.raises(NotImplementedError):
-        so.add_description([("sphere", (0, 0, 1), 0.5, ("refractive", (1, 1, 1), 1.5))])
-    with pytest.raises(NotImplementedError):
-        so.create_sphere((0, 0, 1), 0.5, rt.Material.create_checkerboard((1, 1, 1), (0, 0, 0), 4, 0))
     assert so.num_objects == 0
+    # an IMAGE material without texels is refused, never dereferenced
+    bad = rt.Material.create_image(np.zeros((2, 2, 3), np.float32), 0)
+    bad.c.img_w = 0
+    with pytest.raises(ValueError):
+        so.create_sphere((0, 0, 1), 0.5, bad)
+
+
+def test_baked_texture_file(rt, tmp_path):
+    """ImageTexture src/main.cu:40-91 on the textures/parse_textures.py format"""
+    img = rt.scenes.procedural_image(5, 3)
+    p = tmp_path / "parsed_textures.txt"
+    with open(p, "w") as f:
+        f.write("other.png\n1\n1\n0.5 0.5 0.5 \n")
+        f.write("earth.png\n5\n3\n" + "".join("%s %s %s " % tuple(repr(float(c)) for c in px) for row in img for px in row) + "\n")
+    got = rt.load_image_texture(str(p), "earth.png")
+    assert got.shape == (3, 5, 3) and np.array_equal(got, img)
+    with pytest.raises(rt.RayTracerError, match="Image file not found"):
+        rt.load_image_texture(str(p), "mars.png")
+    with pytest.raises(rt.RayTracerError, match="Could not find file to open"):
+        rt.load_image_texture(str(tmp_path / "nope.txt"), "earth.png")
 
 
 def test_ragged_obj_text(rt, tmp_path):

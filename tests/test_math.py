@@ -54,3 +54,20 @@ def test_math_known_answer_bits(orc):
         f = getattr(L, "orc_math_" + fname)
         got = np.array([f(float(x), orc.MATH_DET) for x in xs], np.float32).view(np.uint32)
         assert np.array_equal(got, kat[fname]), fname
+
+
+def test_asin_acos_accuracy_and_known_answers(orc):
+    """binary64 asin / acos used by the refraction code (src/ray.cu:101-102) and, rounded to
+    float, by the sphere texture coordinates (src/objects.cu:84-85)"""
+    L = orc.lib()
+    xs = np.linspace(-1, 1, 4001)
+    a = np.array([L.orc_math_asin(float(x), orc.MATH_DET) for x in xs])
+    c = np.array([L.orc_math_acos(float(x), orc.MATH_DET) for x in xs])
+    assert np.abs(a - np.arcsin(xs)).max() < 1e-15 and np.abs(c - np.arccos(xs)).max() < 1e-15
+    assert L.orc_math_asin(1.0, orc.MATH_DET) == np.pi / 2 and L.orc_math_acos(1.0, orc.MATH_DET) == 0.0
+    assert np.isnan(L.orc_math_asin(1.0000001, orc.MATH_DET)) and np.isnan(L.orc_math_acos(-2.0, orc.MATH_DET))
+    kat = np.load(os.path.join(GOLDEN, "math_kat.npz"))
+    for name in ("asin", "acos"):
+        f = getattr(L, "orc_math_" + name)
+        got = np.array([f(float(x), orc.MATH_DET) for x in kat["xs_inv"]], np.float64).view(np.uint64)
+        assert np.array_equal(got, kat[name]), name

@@ -23,7 +23,8 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 os.makedirs(GOLD, exist_ok=True)
 md = rt.scenes.models_dir()
 
-SCENES = [("three_sphere", 4), ("cube", 8), ("monkey", 8), ("reference_scene0", 5), ("reference_scene1", 5)]
+SCENES = [("three_sphere", 4), ("cube", 8), ("monkey", 8), ("reference_scene0", 5), ("reference_scene1", 5),
+          ("reference_scene2", 5), ("reference_scene3", 5), ("reference_scene4", 5)]
 meta = {"time_ms": 12345, "frame_num": 0, "antialias": True, "generator": "tools/make_golden.py",
         "python": platform.python_version(), "libc": " ".join(platform.libc_ver()), "frames": {}, "sha256_256x256_s16": {}}
 
@@ -67,6 +68,10 @@ kat = {"xs_log": xs_log, "xs_trig": xs_trig}
 for fname, xs in (("logf", xs_log), ("cosf", xs_trig), ("sinf", xs_trig), ("tanf", xs_trig)):
     f = getattr(L, "orc_math_" + fname)
     kat[fname] = np.array([f(float(x), B.MATH_DET) for x in xs], np.float32).view(np.uint32)
+xs_inv = np.concatenate([rng.uniform(-1, 1, 2000), np.array([-1.0, -0.5, 0.0, 0.5, 1.0, 0.5000001, 0.9999999, 1e-9])])
+kat["xs_inv"] = xs_inv
+kat["asin"] = np.array([L.orc_math_asin(float(x), B.MATH_DET) for x in xs_inv], np.float64).view(np.uint64)
+kat["acos"] = np.array([L.orc_math_acos(float(x), B.MATH_DET) for x in xs_inv], np.float64).view(np.uint64)
 np.savez_compressed(os.path.join(GOLD, "math_kat.npz"), **kat)
 
 with open(os.path.join(GOLD, "meta.json"), "w") as fh:
