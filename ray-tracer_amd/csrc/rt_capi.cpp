@@ -17,7 +17,7 @@
 
 #include "rt_host.h"
 
-extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh, int threads, int blocks, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t rt_launch_rgba8(const float *rgb, int n_pixels, uint8_t *out, hipStream_t stream);
 
 #define RT_LDS_LIMIT 163840   /* 160 KiB per CU / per workgroup on gfx950 */
@@ -33,6 +33,7 @@ struct rt_ctx {
     float *d_prev = nullptr, *d_out = nullptr;
     size_t frame_bytes = 0;
     int work_threshold = 4;      /* lanes; RT_AMD_WORK_THRESHOLD overrides (tuning: tools/ab_threshold.py) */
+    int ready_break = 65;        /* lanes; RT_AMD_READY_BREAK overrides; 65 = never */
 };
 
 struct rt_scene {
@@ -43,6 +44,7 @@ struct rt_scene {
     float *d_tex = nullptr;
     FlatScene flat;          /* host copy (sizes, offsets) */
     int threads = 0;         /* workgroup size chosen for this scene */
+    int scene_in_lds = 1;    /* 0: scene read from global memory (does not fit LDS) */
     size_t lds_bytes = 0;
 };
 
@@ -87,6 +89,7 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return RT_ERR_NO_DEVICE; }
     ctx->num_cus = prop.multiProcessorCount;
     if (const char *e = getenv("RT_AMD_WORK_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->work_threshold = v; }
+    if (const char *e = getenv("RT_AMD_READY_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->ready_break = v; }
     if (hipMalloc((void **)&ctx->tile_counter, 512) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
         rt_ctx_destroy(ctx);
@@ -133,9 +136,17 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
             if (blob_bytes + per_thread * (size_t)nt <= RT_LDS_LIMIT) { s->threads = nt; s->lds_bytes = blob_bytes + per_thread * (size_t)nt; break; }
         }
     }
+    s->scene_in_lds = 1;
     if (s->threads == 0) {
-        delete s;
-        return set_err(ctx, RT_ERR_UNSUPPORTED, "scene does not fit the 160 KiB LDS of a compute unit (" + std::to_string(blob_bytes) + " bytes)");
+        /* larger than a CU's LDS: the kernel reads the scene from global memory (L2-resident),
+         * LDS holds only the traversal stacks */
+        s->scene_in_lds = 0;
+        s->threads = s->flat.has_mesh ? 1024 : 256;
+        s->lds_bytes = per_thread * (size_t)s->threads;
+        if (s->lds_bytes > RT_LDS_LIMIT) {
+            delete s;
+            return set_err(ctx, RT_ERR_UNSUPPORTED, "BVH too deep for the per-lane LDS traversal stack");
+        }
     }
 
     (void)hipSetDevice(ctx->device);
@@ -178,7 +189,7 @@ extern "C" rt_status rt_scene_get_info(const rt_scene *s, rt_scene_info *out)
     out->num_triangles = s->flat.num_tris;
     out->num_nodes = s->flat.num_nodes;
     out->lds_bytes = (int32_t)s->lds_bytes;
-    out->scene_in_lds = 1;
+    out->scene_in_lds = s->scene_in_lds;
     out->threads_per_block = s->threads;
     out->stack_entries = s->flat.stack_entries;
     return RT_OK;
@@ -240,6 +251,7 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     a.num_meshes = scene->flat.num_meshes;
     a.stack_entries = scene->flat.stack_entries;
     a.work_threshold = ctx->work_threshold;
+    a.ready_break = ctx->ready_break;
     a.tri_uv = scene->d_tri_uv;
     a.tex_data = scene->d_tex;
     a.prev = d_prev;
@@ -261,7 +273,7 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
         int needed = (a.num_tiles + waves_per_block - 1) / waves_per_block;
         if (blocks > needed) blocks = needed;
         RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 256, stream), "clearing tile counter");
-        RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
+        RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream), "recording stop event");
     ctx->have_timing = true;

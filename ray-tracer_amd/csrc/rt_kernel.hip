@@ -142,22 +142,35 @@ enum { ST_ITER = 0, ST_SHADE = 1, ST_SHADE_HIT = 2, ST_FETCH = 3, ST_GEN = 4, ST
 /* lane states of the render loop */
 enum { M_FETCH = 0, M_GEN = 1, M_MESH = 2, M_WAIT = 3, M_SHADE = 4, M_DONE = 5 };
 
-template <int NT, bool HAS_MESH>
+/* SCENE_LDS = false is the fallback for scenes larger than a CU's LDS: the same code reads the
+ * scene sections from global memory (they stay L2 / Infinity-Cache resident) and only the
+ * traversal stack lives in LDS. */
+template <int NT, bool HAS_MESH, bool SCENE_LDS>
 __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
 {
     extern __shared__ v4f lds_raw[];
     const int tid = threadIdx.x;
     const int lane = tid & (RT_WAVE - 1);
 
-    /* stage the scene into LDS: coalesced 16-byte loads, one pass per workgroup */
-    for (int i = tid; i < a.blob_f4; i += NT) lds_raw[i] = ((const v4f *)a.blob)[i];
     Lds L;
-    L.nodes = lds_raw + a.off_nodes;
-    L.tris = lds_raw + a.off_tris;
-    L.objs = lds_raw + a.off_objlds;
-    L.meshes = lds_raw + a.off_meshes;
-    L.objtab = lds_raw + a.off_objtab;
-    L.stack = (uint2 *)(lds_raw + a.blob_f4);
+    if (SCENE_LDS) {
+        /* stage the scene into LDS: coalesced 16-byte loads, one pass per workgroup */
+        for (int i = tid; i < a.blob_f4; i += NT) lds_raw[i] = ((const v4f *)a.blob)[i];
+        L.nodes = lds_raw + a.off_nodes;
+        L.tris = lds_raw + a.off_tris;
+        L.objs = lds_raw + a.off_objlds;
+        L.meshes = lds_raw + a.off_meshes;
+        L.objtab = lds_raw + a.off_objtab;
+        L.stack = (uint2 *)(lds_raw + a.blob_f4);
+    } else {
+        const v4f *g = (const v4f *)a.blob;
+        L.nodes = g + a.off_nodes;
+        L.tris = g + a.off_tris;
+        L.objs = g + a.off_objlds;
+        L.meshes = g + a.off_meshes;
+        L.objtab = g + a.off_objtab;
+        L.stack = (uint2 *)lds_raw;
+    }
     __syncthreads();
 
     const V3 cam_pos = v3(a.cam[0], a.cam[1], a.cam[2]);
@@ -508,8 +521,8 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
             for (;;) {
                 const int n_active = __popcll(__ballot(w_active));
                 if (n_active == 0) break;
-                const bool other_ready = __ballot(mode != M_WAIT && mode != M_DONE) != 0ull;
-                if (n_active < a.work_threshold && other_ready) break;
+                const int n_ready = __popcll(__ballot(mode != M_WAIT && mode != M_DONE));
+                if (n_ready > 0 && (n_active < a.work_threshold || n_ready >= a.ready_break)) break;
                 if (w_active) {
                     RT_STAT(ST_WORK_ITER);
                     /* one macro step: descend to a leaf (or run out of children), test the
@@ -610,17 +623,26 @@ __global__ void rt_rgba8_kernel(const float *rgb, int n_pixels, uint8_t *out)
 }
 
 /* ---- launchers (called from rt_capi.cpp) -------------------------------------------------- */
-extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh, int threads, int blocks, size_t lds_bytes, hipStream_t stream)
+template <int NT, bool HAS_MESH, bool SCENE_LDS>
+static void rt_launch_one(const rt_kernel_args *args, int blocks, size_t lds_bytes, hipStream_t stream)
 {
+    (void)hipFuncSetAttribute((const void *)rt_render_kernel<NT, HAS_MESH, SCENE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((rt_render_kernel<NT, HAS_MESH, SCENE_LDS>), dim3(blocks), dim3(NT), lds_bytes, stream, *args);
+}
+
+extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream)
+{
+    if (!scene_in_lds) {
+        /* global-memory scene: one shape per mesh flag is enough */
+        if (has_mesh && threads == 1024) rt_launch_one<1024, true, false>(args, blocks, lds_bytes, stream);
+        else if (!has_mesh && threads == 256) rt_launch_one<256, false, false>(args, blocks, lds_bytes, stream);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
 #define RT_CASE(NTV)                                                                                   \
     case NTV:                                                                                          \
-        if (has_mesh) {                                                                                \
-            (void)hipFuncSetAttribute((const void *)rt_render_kernel<NTV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-            hipLaunchKernelGGL((rt_render_kernel<NTV, true>), dim3(blocks), dim3(NTV), lds_bytes, stream, *args);  \
-        } else {                                                                                       \
-            (void)hipFuncSetAttribute((const void *)rt_render_kernel<NTV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-            hipLaunchKernelGGL((rt_render_kernel<NTV, false>), dim3(blocks), dim3(NTV), lds_bytes, stream, *args); \
-        }                                                                                              \
+        if (has_mesh) rt_launch_one<NTV, true, true>(args, blocks, lds_bytes, stream);                 \
+        else rt_launch_one<NTV, false, true>(args, blocks, lds_bytes, stream);                         \
         break;
     switch (threads) {
         RT_CASE(256)

@@ -297,3 +297,21 @@ def test_textured_and_refractive_primitives(rt, orc, ctx, models_dir):
     want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(200, 120).floats(), 200, 120, 8, 10, sky)
     assert eq(got, want)
     assert np.isfinite(got).all()
+
+
+def test_scene_larger_than_lds_uses_global_memory(rt, orc, ctx, models_dir):
+    """maximum sizes: a 6,000-triangle mesh (BVH + triangles ~ 350 KB) cannot be staged into a
+    CU's 160 KB LDS; the kernel then reads the scene from global memory and must still match"""
+    rng = np.random.default_rng(9)
+    n = 6000
+    centres = rng.uniform([-1.2, -0.6, 1.2], [1.2, 0.8, 3.5], (n, 3))
+    tris = (centres[:, None, :] + rng.normal(0, 0.05, (n, 3, 3))).astype(np.float32).reshape(n, 9)
+    objs = [("mesh", tris, ("standard", (0.8, 0.7, 0.6), 0.1)),
+            ("sphere", (0, -100.5, 1.5), 100, ("checkerboard", (0.9, 0.9, 0.9), (0.3, 0.3, 0.3), 4000, 0))]
+    scene = ctx.commit(rt.SceneObjects(objs))
+    info = scene.info()
+    assert info["scene_in_lds"] == 0 and info["num_triangles"] == n
+    sky = (0.8, 1.0, 1.0)
+    got = hip_render(rt, ctx, objs, 160, 96, 4, 6, sky)
+    want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(160, 96).floats(), 160, 96, 4, 6, sky)
+    assert eq(got, want)
