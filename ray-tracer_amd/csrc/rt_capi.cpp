@@ -32,8 +32,8 @@ struct rt_ctx {
     /* persistent frame buffers for the host-buffer entry point */
     float *d_prev = nullptr, *d_out = nullptr;
     size_t frame_bytes = 0;
-    int work_threshold = 4;      /* lanes; RT_AMD_WORK_THRESHOLD overrides (tuning: tools/ab_threshold.py) */
-    int ready_break = 65;        /* lanes; RT_AMD_READY_BREAK overrides; 65 = never */
+    int work_threshold = 8;      /* lanes; RT_AMD_WORK_THRESHOLD overrides (tuning: tools/ab_threshold.py) */
+    int ready_break = 24;        /* lanes; RT_AMD_READY_BREAK overrides; 65 = never */
 };
 
 struct rt_scene {

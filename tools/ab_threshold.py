@@ -17,7 +17,7 @@ for th in ths:
     ctxs[th] = (c, c.commit(rt.SceneObjects(objs)))
 out = torch.empty((H, W, 3), device="cuda:0")
 res = {th: [] for th in ths}
-for rnd in range(5):
+for rnd in range(int(os.environ.get("AB_ROUNDS", "5"))):
     for th in ths:
         c, sc = ctxs[th]
         rt.render_device(c, sc, rt.Camera(W, H), rt.RenderData(spp, 8, True, sky), 12345, 0, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
