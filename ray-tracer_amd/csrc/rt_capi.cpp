@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "rt_host.h"
 
@@ -32,7 +33,13 @@ struct rt_ctx {
     /* persistent frame buffers for the host-buffer entry point */
     float *d_prev = nullptr, *d_out = nullptr;
     size_t frame_bytes = 0;
+    /* cached tile order (longest-job-first heuristic) for the last (scene, camera, tile spec) */
+    uint32_t *d_tile_order = nullptr;
+    size_t tile_order_cap = 0;
+    std::vector<uint32_t> order_key;     /* what the cached order was built for */
+    int heavy_first = 1;                 /* RT_AMD_HEAVY_FIRST=0 disables */
     int work_threshold = 8;      /* lanes; RT_AMD_WORK_THRESHOLD overrides (tuning: tools/ab_threshold.py) */
+    int tile_scatter = 1;        /* RT_AMD_TILE_SCATTER=0: hand tiles out in raster order */
     int ready_break = 24;        /* lanes; RT_AMD_READY_BREAK overrides; 65 = never */
 };
 
@@ -45,6 +52,7 @@ struct rt_scene {
     FlatScene flat;          /* host copy (sizes, offsets) */
     int threads = 0;         /* workgroup size chosen for this scene */
     int scene_in_lds = 1;    /* 0: scene read from global memory (does not fit LDS) */
+    uint32_t uid = 0;        /* distinguishes scenes in the tile-order cache (addresses get reused) */
     size_t lds_bytes = 0;
 };
 
@@ -89,6 +97,8 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return RT_ERR_NO_DEVICE; }
     ctx->num_cus = prop.multiProcessorCount;
     if (const char *e = getenv("RT_AMD_WORK_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->work_threshold = v; }
+    if (const char *e = getenv("RT_AMD_TILE_SCATTER")) ctx->tile_scatter = atoi(e) != 0;
+    if (const char *e = getenv("RT_AMD_HEAVY_FIRST")) ctx->heavy_first = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_READY_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->ready_break = v; }
     if (hipMalloc((void **)&ctx->tile_counter, 512) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
@@ -106,6 +116,7 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     if (ctx->tile_counter) (void)hipFree(ctx->tile_counter);
     if (ctx->d_prev) (void)hipFree(ctx->d_prev);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;
@@ -120,6 +131,8 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
     rt_scene *s = new (std::nothrow) rt_scene();
     if (!s) return RT_ERR_NOMEM;
     s->ctx = ctx;
+    static uint32_t next_uid = 1;
+    s->uid = next_uid++;
     std::string err = rt_flatten(*b, s->flat);
     if (!err.empty()) { delete s; return set_err(ctx, RT_ERR_UNSUPPORTED, err); }
 
@@ -239,6 +252,75 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     a.tiles_x = (cam->width + 7) / 8;
     const int owned_rows = rt_tile_owned_rows(t, cam->height);
     a.num_tiles = (owned_rows / 8) * a.tiles_x;
+    {
+        /* a stride near num_tiles / golden ratio, made coprime to num_tiles */
+        auto gcd = [](uint32_t x, uint32_t y) { while (y) { uint32_t t = x % y; x = y; y = t; } return x; };
+        auto coprime_stride = [&](uint32_t n) {
+            if (n <= 2u) return 1u;
+            uint32_t st = (uint32_t)(n * 0.6180339887) | 1u;
+            while (gcd(st, n) != 1u) st += 2u;
+            return st % n ? st % n : 1u;
+        };
+        const uint32_t n = a.num_tiles > 0 ? (uint32_t)a.num_tiles : 1u;
+        a.tile_stride = ctx->tile_scatter ? coprime_stride(n) : 1u;
+        a.tile_order = nullptr;
+        if (ctx->heavy_first && ctx->tile_scatter && scene->flat.num_meshes > 0 && a.num_tiles > 1) {
+            /* longest-job-first: tiles whose centre ray enters a mesh root box are handed out
+             * first.  Host float math, a heuristic only: any order renders the same image. */
+            std::vector<uint32_t> key;
+            key.push_back(scene->uid);
+            for (int i = 0; i < 12; i++) { uint32_t u; std::memcpy(&u, &a.cam[i], 4); key.push_back(u); }
+            key.push_back((uint32_t)a.width); key.push_back((uint32_t)a.height);
+            key.push_back((uint32_t)a.band_rows); key.push_back((uint32_t)a.band_first); key.push_back((uint32_t)a.band_stride);
+            if (key != ctx->order_key || !ctx->d_tile_order) {
+                std::vector<uint32_t> heavy, light;
+                const int tiles_per_band = a.tiles_x * (a.band_rows >> 3);
+                for (uint32_t t = 0; t < n; t++) {
+                    const int band_local = (int)t / tiles_per_band, in_band = (int)t % tiles_per_band;
+                    const int band = a.band_first + band_local * a.band_stride;
+                    const int ty = in_band / a.tiles_x, tx = in_band % a.tiles_x;
+                    const float px = tx * 8 + 4.0f, py = band * a.band_rows + ty * 8 + 4.0f;
+                    float d[3], o[3];
+                    for (int k = 0; k < 3; k++) { o[k] = a.cam[k]; d[k] = a.cam[3 + k] + a.cam[6 + k] * px + a.cam[9 + k] * py - o[k]; }
+                    bool hit = false;
+                    for (size_t m = 0; m < scene->flat.objects.size() && !hit; m++) {
+                        const rt_object &ob = scene->flat.objects[m];
+                        if (ob.type != RT_OBJ_MESH) continue;
+                        float tmin = 0.0f, tmax = 3.0e38f;
+                        for (int k = 0; k < 3; k++) {
+                            /* grow the box by a margin: the tile is 8 pixels wide and paths leave it */
+                            const float ext = 0.15f * (ob.v[3 + k] - ob.v[k]) + 1e-3f;
+                            const float inv = 1.0f / d[k];
+                            float t1 = (ob.v[k] - ext - o[k]) * inv, t2 = (ob.v[3 + k] + ext - o[k]) * inv;
+                            if (t1 > t2) { float s = t1; t1 = t2; t2 = s; }
+                            if (t1 > tmin) tmin = t1;
+                            if (t2 < tmax) tmax = t2;
+                        }
+                        hit = tmin <= tmax;
+                    }
+                    (hit ? heavy : light).push_back(t);
+                }
+                std::vector<uint32_t> order;
+                order.reserve(n);
+                for (const std::vector<uint32_t> *cls : {&heavy, &light}) {
+                    const uint32_t m = (uint32_t)cls->size();
+                    const uint32_t st = coprime_stride(m);
+                    for (uint32_t i = 0; i < m; i++) order.push_back((*cls)[(size_t)(((uint64_t)i * st) % m)]);
+                }
+                if (ctx->tile_order_cap < n) {
+                    if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
+                    ctx->d_tile_order = nullptr;
+                    ctx->tile_order_cap = 0;
+                    RT_HIP(ctx, hipMalloc((void **)&ctx->d_tile_order, (size_t)n * 4), "allocating tile order");
+                    ctx->tile_order_cap = n;
+                }
+                RT_HIP(ctx, hipMemcpyAsync(ctx->d_tile_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream), "uploading tile order");
+                RT_HIP(ctx, hipStreamSynchronize(stream), "uploading tile order");     /* `order` is a local */
+                ctx->order_key = key;
+            }
+            a.tile_order = ctx->d_tile_order;
+        }
+    }
     a.objects = scene->d_objects;
     a.num_objects = (int32_t)scene->flat.objects.size();
     a.blob = scene->d_blob;

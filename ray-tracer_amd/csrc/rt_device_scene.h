@@ -99,6 +99,8 @@ typedef struct {
     int32_t band_rows, band_first, band_stride, compact;
     int32_t tiles_x;               /* 8x8 tiles per row of tiles */
     int32_t num_tiles;             /* tiles this launch renders */
+    uint32_t tile_stride;          /* ticket t renders tile (t * tile_stride) % num_tiles; coprime to num_tiles */
+    const uint32_t *tile_order;    /* or, if not NULL, tile tile_order[t] (expensive-looking tiles first) */
     /* scene */
     const rt_object *objects;
     int32_t num_objects;

@@ -374,6 +374,14 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                     if (lane == 0) t = atomicAdd(a.tile_counter, 1u);
                     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
                     if (t >= (uint32_t)a.num_tiles) { exhausted = true; break; }
+                    /* ticket -> tile through a permutation.  A pixel's samples are sequential, so
+                     * the frame cannot finish before its most expensive tile does; the host
+                     * therefore lists the tiles whose centre ray enters a mesh box first
+                     * (longest-job-first), each class scattered by a stride coprime to the tile
+                     * count so that neighbouring (equally expensive) tiles do not land on the
+                     * waves of one CU.  Any order gives the same image. */
+                    t = a.tile_order ? a.tile_order[t]
+                                     : (uint32_t)(((unsigned long long)t * (unsigned long long)a.tile_stride) % (unsigned long long)a.num_tiles);
                     chunk_next = t * 64u;
                     chunk_end = t * 64u + 64u;
                 }

@@ -267,12 +267,20 @@ def test_bench_two_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29600 + os.getpid() % 300), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
-           "--spp", "8", "--backend", "gloo", "--share-gpu", "--check", "--no-cpu-baseline"]
+           "--spp", "8", "--backend", "gloo", "--share-gpu", "--check", "--no-cpu-baseline", "--scaling", "strong"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["unit"] == "Msamples/s" and j["value"] > 0
+    assert j["config"]["image"] == "1920x1080"
+    # default for N > 1: weak scaling, the image area grows with N at the same aspect ratio
+    cmd[cmd.index("--scaling") + 1] = "weak"
+    cmd[cmd.index("--master-port") + 1] = str(29900 + os.getpid() % 90)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["scaling"] == "weak" and j["config"]["image"] == "2720x1530" and j["gathered_equals_single_launch"] is True
     assert j["gathered_equals_single_launch"] is True
     assert "roofline" in j and j["roofline"]["bound"] == "hbm"
 
