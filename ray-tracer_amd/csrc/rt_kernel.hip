@@ -556,16 +556,17 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                             const bool l_push = lh && ld < w_best;
                             const bool r_push = rh2 && rdist < w_best;
                             const bool l_first = ld < rdist;
-                            /* "first" is pushed first and therefore visited second */
-                            const uint32_t first_ref = l_first ? lref : rref, second_ref = l_first ? rref : lref;
-                            const float first_d = l_first ? ld : rdist;
-                            const bool first_push = l_first ? l_push : r_push, second_push = l_first ? r_push : l_push;
-                            L.stack[sp * NT + tid] = make_uint2(__float_as_uint(first_d), first_ref);
-                            sp += (first_push && second_push) ? 1 : 0;
-                            /* the child entered now: `second` (popped immediately, its distance is
-                             * still < best) if it was pushed, else `first` */
-                            const uint32_t next = second_push ? second_ref : first_ref;
-                            const bool entered = first_push || second_push;
+                            /* Of two entered children the one pushed first (left when l_first) is
+                             * visited second: it is the deferred sibling.  The other is popped
+                             * immediately (its distance is still < best).  With one entered child
+                             * that child is next and nothing is deferred. */
+                            const bool both = l_push && r_push;
+                            const bool entered = l_push || r_push;
+                            const uint32_t deferred_ref = l_first ? lref : rref;
+                            const float deferred_d = l_first ? ld : rdist;
+                            L.stack[sp * NT + tid] = make_uint2(__float_as_uint(deferred_d), deferred_ref);
+                            sp += both ? 1 : 0;
+                            const uint32_t next = both ? (l_first ? rref : lref) : (l_push ? lref : rref);
                             cur = entered ? next : cur;
                             at_leaf = entered && (next & RT_REF_LEAF) != 0u;
                             if (!entered || at_leaf) break;
