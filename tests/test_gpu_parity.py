@@ -323,3 +323,66 @@ def test_scene_larger_than_lds_uses_global_memory(rt, orc, ctx, models_dir):
     got = hip_render(rt, ctx, objs, 160, 96, 4, 6, sky)
     want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(160, 96).floats(), 160, 96, 4, 6, sky)
     assert eq(got, want)
+
+
+def _random_scene(seed):
+    """a seeded mix of every primitive and material kind, in random list order"""
+    rng = np.random.default_rng(seed)
+
+    def vec(lo, hi):
+        return tuple(float(x) for x in rng.uniform(lo, hi, 3))
+
+    def material():
+        k = rng.integers(0, 7)
+        col = vec(0.1, 1.0)
+        if k == 0:
+            return ("standard", col, float(rng.uniform(0, 1)))
+        if k == 1:
+            return ("standard", col, 0.0)
+        if k == 2:
+            return ("emissive", col, float(rng.uniform(0.5, 5)))
+        if k == 3:
+            return ("checkerboard", col, vec(0, 0.5), int(rng.integers(1, 12)), float(rng.uniform(0, 0.5)))
+        if k == 4:
+            return ("gradient", float(rng.uniform(0, 0.3)))
+        if k == 5:
+            return ("refractive", col, float(rng.uniform(1.05, 2.2)))
+        return ("image", rng.uniform(0, 1, (int(rng.integers(2, 9)), int(rng.integers(2, 9)), 3)).astype(np.float32), 0.0)
+
+    objs = []
+    for _ in range(int(rng.integers(6, 14))):
+        kind = rng.integers(0, 7)
+        c = np.array(vec([-1.2, -0.7, 1.0], [1.2, 0.9, 3.5]))
+        if kind == 0:
+            objs.append(("sphere", tuple(c), float(rng.uniform(0.08, 0.45)), material()))
+        elif kind == 1:
+            p = [tuple(c + rng.normal(0, 0.35, 3)) for _ in range(3)]
+            objs.append(("triangle_uv", p, [tuple(rng.uniform(0, 1, 2)) for _ in range(3)], material()))
+        elif kind == 2:
+            a, b = rng.normal(0, 0.4, 3), rng.normal(0, 0.4, 3)
+            objs.append(("quad", tuple(c), tuple(c + a), tuple(c + a + b), tuple(c + b), material()))
+        elif kind == 3:
+            a, b = rng.normal(0, 0.5, 3), rng.normal(0, 0.5, 3)
+            objs.append(("one_way_quad", tuple(c), tuple(c + a), tuple(c + a + b), tuple(c + b), bool(rng.integers(0, 2)), material()))
+        elif kind == 4:
+            objs.append(("cuboid", tuple(c), float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.1, 0.5)), material()))
+        elif kind == 5:
+            objs.append(("obj", "cube.obj", [("enlarge", float(rng.uniform(0.08, 0.25))), ("rotate", *[float(x) for x in rng.uniform(-3, 3, 3)]),
+                                             ("translate", *[float(x) for x in c])], material()))
+        else:
+            n = int(rng.integers(1, 60))
+            tris = (c + rng.normal(0, 0.25, (n, 1, 3)) + rng.normal(0, 0.08, (n, 3, 3))).astype(np.float32).reshape(n, 9)
+            objs.append(("mesh", tris, material()))
+    if rng.integers(0, 2):
+        objs.append(("sphere", (0, -100.5, 1.5), 100, ("standard", (0.5, 0.5, 0.5), float(rng.uniform(0, 0.4)))))
+    sky = (0.8, 1.0, 1.0) if rng.integers(0, 2) else (0.0, 0.0, 0.0)
+    return objs, sky
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_random_mixed_scenes(rt, orc, ctx, models_dir, seed):
+    objs, sky = _random_scene(seed)
+    W, H, spp, limit = 112 + 8 * (seed % 3), 72, 5, 3 + seed % 6
+    got = hip_render(rt, ctx, objs, W, H, spp, limit, sky, time_ms=1000 + seed)
+    want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(W, H).floats(), W, H, spp, limit, sky, time_ms=1000 + seed)
+    assert eq(got, want)
