@@ -39,6 +39,7 @@ struct rt_ctx {
     std::vector<uint32_t> order_key;     /* what the cached order was built for */
     int heavy_first = 1;                 /* RT_AMD_HEAVY_FIRST=0 disables */
     int work_threshold = 8;      /* lanes; RT_AMD_WORK_THRESHOLD overrides (tuning: tools/ab_threshold.py) */
+    int descend_keep = 24;       /* RT_AMD_DESCEND_KEEP (0..64): 0 = run every descent to its end */
     int tile_scatter = 1;        /* RT_AMD_TILE_SCATTER=0: hand tiles out in raster order */
     int ready_break = 24;        /* lanes; RT_AMD_READY_BREAK overrides; 65 = never */
 };
@@ -97,6 +98,7 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return RT_ERR_NO_DEVICE; }
     ctx->num_cus = prop.multiProcessorCount;
     if (const char *e = getenv("RT_AMD_WORK_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->work_threshold = v; }
+    if (const char *e = getenv("RT_AMD_DESCEND_KEEP")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->descend_keep = v; }
     if (const char *e = getenv("RT_AMD_TILE_SCATTER")) ctx->tile_scatter = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_HEAVY_FIRST")) ctx->heavy_first = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_READY_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->ready_break = v; }
@@ -334,6 +336,7 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     a.stack_entries = scene->flat.stack_entries;
     a.work_threshold = ctx->work_threshold;
     a.ready_break = ctx->ready_break;
+    a.descend_keep = ctx->descend_keep;
     a.tri_uv = scene->d_tri_uv;
     a.tex_data = scene->d_tex;
     a.prev = d_prev;

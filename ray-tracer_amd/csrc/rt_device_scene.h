@@ -110,6 +110,7 @@ typedef struct {
     int32_t num_meshes;
     int32_t stack_entries;         /* per-lane traversal stack depth (LDS) */
     int32_t work_threshold;        /* run traversal steps while at least this many lanes traverse */
+    int32_t descend_keep;          /* leave the descend loop when fewer than descend_keep/64 of its lanes remain */
     int32_t ready_break;           /* ... unless at least this many lanes are ready to shade / generate */
     const float *tri_uv;           /* 6 floats per triangle, or NULL */
     const float *tex_data;         /* IMAGE texture texels (rgb floats), or NULL */

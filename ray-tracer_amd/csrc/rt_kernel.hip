@@ -540,11 +540,18 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                      * branches lengthen each wave's serial instruction stream, and at the 4
                      * waves/SIMD an LDS-resident scene allows that latency is not hidden.) */
                     bool at_leaf = (cur & RT_REF_LEAF) != 0u;
+                    bool need_pop = at_leaf;
                     if (!at_leaf) {
                         /* The body is branch-free: the deferred sibling is ALWAYS written to the
                          * slot above the top of the stack (one 8-byte LDS store) and the stack
                          * pointer moves only when both children are entered, so the only
-                         * divergent branch of the loop is its exit. */
+                         * divergent branch of the loop is its exit.  The loop also ends, for
+                         * everybody, once fewer than `descend_keep`/64 of the lanes that entered
+                         * it are still descending: those lanes just stay on their internal node
+                         * and go on next step, instead of making the others wait out the deepest
+                         * descent of the wave. */
+                        const int n_enter = __popcll(__ballot(1));
+                        const int n_keep = (n_enter * a.descend_keep) >> 6;
                         for (;;) {
                             RT_STAT(ST_NODE);
                             const v4f *n = L.nodes + 4 * (int)(cur & RT_REF_NODE_MASK);
@@ -569,7 +576,9 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                             const uint32_t next = both ? (l_first ? rref : lref) : (l_push ? lref : rref);
                             cur = entered ? next : cur;
                             at_leaf = entered && (next & RT_REF_LEAF) != 0u;
-                            if (!entered || at_leaf) break;
+                            need_pop = !entered || at_leaf;
+                            if (need_pop) break;
+                            if (__popcll(__ballot(1)) < n_keep) break;      /* wave-uniform */
                         }
                     }
                     if (at_leaf) {
@@ -585,8 +594,8 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                     }
                     /* pop: an entry is taken iff !(dist > best) (:501); through a collapsed chain
                      * iff dist < best (:517) */
-                    bool found = false;
-                    while (sp > 0) {
+                    bool found = !need_pop;                 /* still descending: nothing to pop */
+                    while (need_pop && sp > 0) {
                         RT_STAT(ST_POP);
                         sp--;
                         const uint2 e = L.stack[sp * NT + tid];

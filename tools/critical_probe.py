@@ -13,7 +13,9 @@ objs, sky = rt.scenes.monkey()
 cam, rd = rt.Camera(W, H), rt.RenderData(spp, 8, True, sky)
 ctxs = []
 for s in sets:
-    os.environ["RT_AMD_WORK_THRESHOLD"], os.environ["RT_AMD_READY_BREAK"] = s.split(":")
+    parts = s.split(":")
+    os.environ["RT_AMD_WORK_THRESHOLD"], os.environ["RT_AMD_READY_BREAK"] = parts[0], parts[1]
+    os.environ["RT_AMD_DESCEND_KEEP"] = parts[2] if len(parts) > 2 else "0"
     c = rt.Context(0)
     ctxs.append((c, c.commit(rt.SceneObjects(objs))))
 res = {s: ([], []) for s in sets}
