@@ -266,11 +266,11 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
         const uint32_t n = a.num_tiles > 0 ? (uint32_t)a.num_tiles : 1u;
         a.tile_stride = ctx->tile_scatter ? coprime_stride(n) : 1u;
         a.tile_order = nullptr;
-        if (ctx->heavy_first && ctx->tile_scatter && scene->flat.num_meshes > 0 && a.num_tiles > 1) {
+        if (ctx->heavy_first && scene->flat.num_meshes > 0 && a.num_tiles > 1) {
             /* longest-job-first: tiles whose centre ray enters a mesh root box are handed out
              * first.  Host float math, a heuristic only: any order renders the same image. */
             std::vector<uint32_t> key;
-            key.push_back(scene->uid);
+            key.push_back(scene->uid); key.push_back((uint32_t)ctx->tile_scatter);
             for (int i = 0; i < 12; i++) { uint32_t u; std::memcpy(&u, &a.cam[i], 4); key.push_back(u); }
             key.push_back((uint32_t)a.width); key.push_back((uint32_t)a.height);
             key.push_back((uint32_t)a.band_rows); key.push_back((uint32_t)a.band_first); key.push_back((uint32_t)a.band_stride);
@@ -306,7 +306,7 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
                 order.reserve(n);
                 for (const std::vector<uint32_t> *cls : {&heavy, &light}) {
                     const uint32_t m = (uint32_t)cls->size();
-                    const uint32_t st = coprime_stride(m);
+                    const uint32_t st = ctx->tile_scatter ? coprime_stride(m) : 1u;
                     for (uint32_t i = 0; i < m; i++) order.push_back((*cls)[(size_t)(((uint64_t)i * st) % m)]);
                 }
                 if (ctx->tile_order_cap < n) {
