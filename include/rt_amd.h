@@ -201,6 +201,11 @@ typedef struct rt_flat_view {
     const float *tri_uv; int32_t num_triangles, num_nodes, has_mesh;
 } rt_flat_view;
 rt_status rt_debug_flatten(rt_scene_builder *b, rt_flat_view *out);
+/* evaluates one function of the shared math / RNG headers ON THE DEVICE, element-wise, on raw
+ * 32-bit patterns (host pointers).  op: 0 rt_logf, 1 rt_cosf, 2 rt_sinf, 3 rt_asinf, 4 rt_acosf,
+ * 5 rt_u01, 6 rt_jitter, 7 rt_theta (5-7 take the uint32 hash output), 8 sqrtf, 9 1.0f/x,
+ * 10 (float)rt_pow5 */
+rt_status rt_debug_eval(rt_ctx *ctx, int32_t op, const uint32_t *in, uint32_t *out, int32_t n);
 /* section counters of a development build compiled with -DRT_STATS (all zero otherwise) */
 rt_status rt_debug_read_stats(rt_ctx *ctx, unsigned long long *out24);
 

@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "rt_obj_num_triangles", "rt_obj_get_triangles", "rt_camera_default", "rt_camera_make",
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_commit", "rt_scene_destroy",
     "rt_scene_get_info", "rt_render", "rt_render_device", "rt_tile_owned_rows", "rt_last_kernel_ms",
-    "rt_to_rgba8_device", "rt_debug_flatten", "rt_debug_read_stats", "rt_version",
+    "rt_to_rgba8_device", "rt_debug_flatten", "rt_debug_read_stats", "rt_debug_eval", "rt_version",
 ]
 
 _lib = None
@@ -162,6 +162,7 @@ def lib():
     L.rt_to_rgba8_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
     L.rt_debug_flatten.argtypes = [vp, C.POINTER(rt_flat_view)]
     L.rt_debug_read_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.rt_debug_eval.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int32]
     L.rt_version.restype = C.c_char_p
     _lib = L
     return L
@@ -572,6 +573,14 @@ def render_device(ctx, scene, camera, render_data, time_ms, frame_num, d_out, d_
     ts = rt_tile_spec(int(band_rows), int(band_first), int(band_stride), int(bool(compact)))
     ctx._check(lib().rt_render_device(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), int(time_ms), int(frame_num),
                                       C.byref(ts), C.c_void_p(d_prev or 0), C.c_void_p(d_out), C.c_void_p(stream or 0)))
+
+
+def debug_eval(ctx, op, bits):
+    """device-side evaluation of a math / RNG header function on uint32 bit patterns (tests)"""
+    a = np.ascontiguousarray(bits, dtype=np.uint32)
+    out = np.empty_like(a)
+    ctx._check(lib().rt_debug_eval(ctx._h, int(op), a.ctypes.data_as(C.POINTER(C.c_uint32)), out.ctypes.data_as(C.POINTER(C.c_uint32)), a.size))
+    return out
 
 
 def tile_owned_rows(height, band_rows=8, band_first=0, band_stride=1):

@@ -19,6 +19,7 @@
 #include "rt_host.h"
 
 extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t rt_launch_eval(int op, const uint32_t *in, uint32_t *out, int n, hipStream_t stream);
 extern "C" hipError_t rt_launch_rgba8(const float *rgb, int n_pixels, uint8_t *out, hipStream_t stream);
 
 #define RT_LDS_LIMIT 163840   /* 160 KiB per CU / per workgroup on gfx950 */
@@ -362,6 +363,25 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream), "recording stop event");
     ctx->have_timing = true;
+    return RT_OK;
+}
+
+/* test hook: evaluates one function of rt_math.h / rt_rng.h on the DEVICE for n inputs given
+ * and returned as raw 32-bit patterns in host memory */
+extern "C" rt_status rt_debug_eval(rt_ctx *ctx, int32_t op, const uint32_t *in, uint32_t *out, int32_t n)
+{
+    if (!ctx || !in || !out || n <= 0 || op < 0 || op > 10) return set_err(ctx, RT_ERR_INVALID, "bad argument");
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    RT_HIP(ctx, hipMalloc((void **)&d_in, (size_t)n * 4), "allocating eval input");
+    hipError_t e = hipMalloc((void **)&d_out, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rt_launch_eval(op, d_in, d_out, n, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return hip_fail(ctx, e, "evaluating on the device");
     return RT_OK;
 }
 

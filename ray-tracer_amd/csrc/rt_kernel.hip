@@ -640,6 +640,38 @@ __global__ void rt_rgba8_kernel(const float *rgb, int n_pixels, uint8_t *out)
     ((uint32_t *)out)[i] = packed;
 }
 
+/* Element-wise evaluation of the shared math / RNG headers on the device, for the test that
+ * checks them bit for bit against the same headers compiled for the host (rt_debug_eval). */
+__global__ void rt_eval_kernel(int op, const uint32_t *in, uint32_t *out, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t u = in[i];
+    const float x = __uint_as_float(u);
+    float r = 0.0f;
+    switch (op) {
+        case 0: r = rt_logf(x); break;
+        case 1: r = rt_cosf(x); break;
+        case 2: r = rt_sinf(x); break;
+        case 3: r = rt_asinf(x); break;
+        case 4: r = rt_acosf(x); break;
+        case 5: r = rt_u01(u); break;
+        case 6: r = rt_jitter(u); break;
+        case 7: r = rt_theta(u); break;
+        case 8: r = sqrtf(x); break;                 /* the IEEE operations parity relies on */
+        case 9: r = 1.0f / x; break;
+        case 10: r = (float)rt_pow5((double)x); break;
+        default: break;
+    }
+    out[i] = __float_as_uint(r);
+}
+
+extern "C" hipError_t rt_launch_eval(int op, const uint32_t *in, uint32_t *out, int n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rt_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, in, out, n);
+    return hipGetLastError();
+}
+
 /* ---- launchers (called from rt_capi.cpp) -------------------------------------------------- */
 template <int NT, bool HAS_MESH, bool SCENE_LDS>
 static void rt_launch_one(const rt_kernel_args *args, int blocks, size_t lds_bytes, hipStream_t stream)

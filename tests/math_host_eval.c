@@ -1,0 +1,31 @@
+/* Host build of ray-tracer_amd/csrc/rt_math.h and rt_rng.h for tests/test_gpu_math.py:
+ * evaluates the same functions the device kernel rt_eval_kernel evaluates, on raw bit patterns.
+ * gcc -O2 -ffp-contract=off -shared -fPIC */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include "../ray-tracer_amd/csrc/rt_math.h"
+#include "../ray-tracer_amd/csrc/rt_rng.h"
+
+void host_eval(int op, const uint32_t *in, uint32_t *out, int n)
+{
+    for (int i = 0; i < n; i++) {
+        uint32_t u = in[i];
+        float x, r = 0.0f;
+        memcpy(&x, &u, 4);
+        switch (op) {
+            case 0: r = rt_logf(x); break;
+            case 1: r = rt_cosf(x); break;
+            case 2: r = rt_sinf(x); break;
+            case 3: r = rt_asinf(x); break;
+            case 4: r = rt_acosf(x); break;
+            case 5: r = rt_u01(u); break;
+            case 6: r = rt_jitter(u); break;
+            case 7: r = rt_theta(u); break;
+            case 8: r = sqrtf(x); break;
+            case 9: r = 1.0f / x; break;
+            case 10: r = (float)rt_pow5((double)x); break;
+        }
+        memcpy(&out[i], &r, 4);
+    }
+}
