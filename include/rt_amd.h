@@ -206,8 +206,8 @@ rt_status rt_debug_flatten(rt_scene_builder *b, rt_flat_view *out);
  * 5 rt_u01, 6 rt_jitter, 7 rt_theta (5-7 take the uint32 hash output), 8 sqrtf, 9 1.0f/x,
  * 10 (float)rt_pow5 */
 rt_status rt_debug_eval(rt_ctx *ctx, int32_t op, const uint32_t *in, uint32_t *out, int32_t n);
-/* section counters of a development build compiled with -DRT_STATS (all zero otherwise) */
-rt_status rt_debug_read_stats(rt_ctx *ctx, unsigned long long *out24);
+/* 48 section counters / timers of a development build compiled with -DRT_STATS (all zero otherwise) */
+rt_status rt_debug_read_stats(rt_ctx *ctx, unsigned long long *out48);
 
 const char *rt_version(void);
 

@@ -42,6 +42,8 @@ struct rt_ctx {
     int work_threshold = 8;      /* lanes; RT_AMD_WORK_THRESHOLD overrides (tuning: tools/ab_threshold.py) */
     int descend_keep = 24;       /* RT_AMD_DESCEND_KEEP (0..64): 0 = run every descent to its end */
     int tile_scatter = 1;        /* RT_AMD_TILE_SCATTER=0: hand tiles out in raster order */
+    int max_waves = 64;          /* RT_AMD_MAX_WAVES, experiment */
+    int chunk_log2 = 6;          /* RT_AMD_CHUNK_LOG2 (2..6), experiment */
     int ready_break = 24;        /* lanes; RT_AMD_READY_BREAK overrides; 65 = never */
 };
 
@@ -102,8 +104,10 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (const char *e = getenv("RT_AMD_DESCEND_KEEP")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->descend_keep = v; }
     if (const char *e = getenv("RT_AMD_TILE_SCATTER")) ctx->tile_scatter = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_HEAVY_FIRST")) ctx->heavy_first = atoi(e) != 0;
+    if (const char *e = getenv("RT_AMD_MAX_WAVES")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->max_waves = v; }
+    if (const char *e = getenv("RT_AMD_CHUNK_LOG2")) { int v = atoi(e); if (v >= 2 && v <= 6) ctx->chunk_log2 = v; }
     if (const char *e = getenv("RT_AMD_READY_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->ready_break = v; }
-    if (hipMalloc((void **)&ctx->tile_counter, 512) != hipSuccess ||
+    if (hipMalloc((void **)&ctx->tile_counter, 1024) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
         rt_ctx_destroy(ctx);
         return RT_ERR_HIP;
@@ -337,13 +341,16 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     a.stack_entries = scene->flat.stack_entries;
     a.work_threshold = ctx->work_threshold;
     a.ready_break = ctx->ready_break;
+    a.chunk_log2 = ctx->chunk_log2;
+    a.max_waves = ctx->max_waves;
+    if (ctx->chunk_log2 < 6) { a.num_tiles <<= (6 - ctx->chunk_log2); a.tile_order = nullptr; a.tile_stride = 1; }
     a.descend_keep = ctx->descend_keep;
     a.tri_uv = scene->d_tri_uv;
     a.tex_data = scene->d_tex;
     a.prev = d_prev;
     a.out = d_out;
     a.tile_counter = ctx->tile_counter;
-    a.stats = (unsigned long long *)(ctx->tile_counter + 16);   /* 24 x u64 after the counter; used by -DRT_STATS builds only */
+    a.stats = (unsigned long long *)(ctx->tile_counter + 16);   /* 48 x u64 after the counter; used by -DRT_STATS builds only */
 
     RT_HIP(ctx, hipEventRecord(ctx->ev_start, stream), "recording start event");
     ctx->have_timing = false;
@@ -357,8 +364,8 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
         }
         int blocks = ctx->num_cus * blocks_per_cu;
         int needed = (a.num_tiles + waves_per_block - 1) / waves_per_block;
-        if (blocks > needed) blocks = needed;
-        RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 256, stream), "clearing tile counter");
+        if (blocks > needed && ctx->max_waves >= 64) blocks = needed;
+        RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 512, stream), "clearing tile counter");
         RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream), "recording stop event");
@@ -385,12 +392,12 @@ extern "C" rt_status rt_debug_eval(rt_ctx *ctx, int32_t op, const uint32_t *in, 
     return RT_OK;
 }
 
-/* development hook: copies the 24 section counters of a -DRT_STATS build (zeros otherwise) */
-extern "C" rt_status rt_debug_read_stats(rt_ctx *ctx, unsigned long long *out24)
+/* development hook: copies the 48 section counters / timers of a -DRT_STATS build (zeros otherwise) */
+extern "C" rt_status rt_debug_read_stats(rt_ctx *ctx, unsigned long long *out48)
 {
-    if (!ctx || !out24) return RT_ERR_INVALID;
+    if (!ctx || !out48) return RT_ERR_INVALID;
     RT_HIP(ctx, hipDeviceSynchronize(), "waiting for render kernel");
-    RT_HIP(ctx, hipMemcpy(out24, ctx->tile_counter + 16, 24 * 8, hipMemcpyDeviceToHost), "reading stats");
+    RT_HIP(ctx, hipMemcpy(out48, ctx->tile_counter + 16, 48 * 8, hipMemcpyDeviceToHost), "reading stats");
     return RT_OK;
 }
 

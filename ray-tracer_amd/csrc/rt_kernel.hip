@@ -137,10 +137,22 @@ __device__ __forceinline__ bool quad_test(const v4f *tris, int first, V3 o, V3 d
 #else
 #define RT_STAT(slot) do { } while (0)
 #endif
+/* ... and (lap timer, s_memtime) where a wave's time goes: RT_LAP(slot) charges the time since the
+ * previous lap to `slot` */
+enum { TM_CTL = 0, TM_SHADE = 1, TM_FETCH = 2, TM_GEN = 3, TM_MESH = 4, TM_DESCEND = 5, TM_LEAF = 6, TM_POP = 7, TM_N = 8 };
+#ifdef RT_STATS
+#define RT_LAP(slot) do { unsigned long long now_ = __builtin_readcyclecounter(); st_time[slot] += now_ - st_last; st_last = now_; } while (0)
+/* inside the divergent `if (w_active)` block: leave it, lap with every lane, enter it again (the
+ * timers are per-lane registers; only laps that all lanes execute measure the wave) */
+#define RT_LAP_SPLIT(slot) } RT_LAP(slot); if (w_active) {
+#else
+#define RT_LAP(slot) do { } while (0)
+#define RT_LAP_SPLIT(slot)
+#endif
 enum { ST_ITER = 0, ST_SHADE = 1, ST_SHADE_HIT = 2, ST_FETCH = 3, ST_GEN = 4, ST_MESH = 5, ST_MESH_START = 6, ST_WORK_ITER = 7, ST_NODE = 8, ST_LEAF_TRI = 9, ST_POP = 10, ST_DONE_MESH = 11, ST_N = 12 };
 
 /* lane states of the render loop */
-enum { M_FETCH = 0, M_GEN = 1, M_MESH = 2, M_WAIT = 3, M_SHADE = 4, M_DONE = 5 };
+enum { M_FETCH = 0, M_GEN = 1, M_MESH = 2, M_WAIT = 3, M_SHADE = 4, M_DONE = 5, M_IDLE = 6 };
 
 /* SCENE_LDS = false is the fallback for scenes larger than a CU's LDS: the same code reads the
  * scene sections from global memory (they stay L2 / Infinity-Cache resident) and only the
@@ -172,6 +184,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
         L.stack = (uint2 *)lds_raw;
     }
     __syncthreads();
+    if ((tid >> 6) >= a.max_waves) return;
 
     const V3 cam_pos = v3(a.cam[0], a.cam[1], a.cam[2]);
     const V3 tl = v3(a.cam[3], a.cam[4], a.cam[5]);
@@ -198,13 +211,25 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
     /* ---- wave-uniform pixel chunk: linear pixel ids [chunk_next, chunk_end) of one 8x8 tile ---- */
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false;
+#ifdef RT_COSTMAP
+    /* development build (tools/costmap.py): the frame holds, per pixel, (own traversal steps,
+     * start tick, end tick) of the 100 MHz wall clock instead of the colour */
+    unsigned c_steps = 0, c_t0 = 0, c_wsteps = 0;
+#define RT_COST(x) do { x; } while (0)
+#else
+#define RT_COST(x) do { } while (0)
+#endif
 #ifdef RT_STATS
     unsigned st_exec[ST_N], st_lanes[ST_N];
     for (int i = 0; i < ST_N; i++) { st_exec[i] = 0; st_lanes[i] = 0; }
+    unsigned long long st_time[TM_N], st_last = __builtin_readcyclecounter();
+    const unsigned long long st_wall0 = wall_clock64();
+    for (int i = 0; i < TM_N; i++) st_time[i] = 0;
 #endif
 
     for (;;) {
         RT_STAT(ST_ITER);
+        RT_LAP(TM_CTL);
         /* ================= SHADE: the closest hit of this bounce is known ================== */
         if (mode == M_SHADE) {
             RT_STAT(ST_SHADE);
@@ -346,16 +371,26 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                         out_row = ((band - a.band_first) / a.band_stride) * a.band_rows + (py - band * a.band_rows);
                     }
                     float *dst = a.out + ((size_t)out_row * (size_t)W + (size_t)px) * 3;
+#ifdef RT_COSTMAP
+                    res = v3(__uint_as_float(RT_COSTMAP == 2 ? c_wsteps : c_steps), __uint_as_float(c_t0), __uint_as_float((unsigned)wall_clock64()));
+#endif
                     dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
                     mode = M_FETCH;
                 }
             }
         }
 
+        RT_LAP(TM_SHADE);
         /* ================= FETCH: lanes without a pixel take the next ones ==================
          * Linear pixel ids are tile-major (64 per 8x8 tile), tiles come from a global counter;
          * a wave asks for one tile at a time and hands its ids out to whichever lanes are free. */
         {
+            if (a.chunk_log2 < 6) {
+                /* experiment: lanes left over by a small ticket sit idle until the wave's pixels are done */
+                const bool busy = __ballot(mode == M_GEN || mode == M_MESH || mode == M_WAIT || mode == M_SHADE) != 0ull;
+                if (busy && mode == M_FETCH) mode = M_IDLE;
+                if (!busy && mode == M_IDLE) mode = M_FETCH;
+            }
             const bool want = mode == M_FETCH;
             const unsigned long long mask = __ballot(want);
             if (mask) {
@@ -363,13 +398,14 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                 int taken = 0;
                 int my_id = -1;
+                bool got_ticket = false;
                 for (;;) {
                     const int avail = (int)(chunk_end - chunk_next);
                     const int take = avail < need - taken ? avail : need - taken;
                     if (want && rank >= taken && rank < taken + take) my_id = (int)chunk_next + (rank - taken);
                     chunk_next += (uint32_t)take;
                     taken += take;
-                    if (taken == need || exhausted) break;
+                    if (taken == need || exhausted || (a.chunk_log2 < 6 && got_ticket)) break;
                     uint32_t t = 0;
                     if (lane == 0) t = atomicAdd(a.tile_counter, 1u);
                     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
@@ -382,12 +418,13 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                      * waves of one CU.  Any order gives the same image. */
                     t = a.tile_order ? a.tile_order[t]
                                      : (uint32_t)(((unsigned long long)t * (unsigned long long)a.tile_stride) % (unsigned long long)a.num_tiles);
-                    chunk_next = t * 64u;
-                    chunk_end = t * 64u + 64u;
+                    chunk_next = t << a.chunk_log2;
+                    chunk_end = chunk_next + (1u << a.chunk_log2);
+                    got_ticket = true;
                 }
                 if (want) {
                     if (my_id < 0) {
-                        mode = M_DONE;
+                        if (exhausted) mode = M_DONE;
                     } else {
                         const int tile = my_id >> 6, within = my_id & 63;
                         const int band_local = tile / tiles_per_band;
@@ -401,6 +438,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                              * cam_pixel_to_world src/camera.cu:24-29 */
                             const int array_index = (py * W + px) * 3;
                             rng = (uint32_t)array_index * 3145739u + a.seed_time;
+                            RT_COST(c_steps = 0; c_wsteps = 0; c_t0 = (unsigned)wall_clock64());
                             V3 plane_point = du * (float)px + dv * (float)py;
                             primary = normalised((tl + plane_point) - cam_pos);
                             colour = v3(0.f, 0.f, 0.f);
@@ -429,6 +467,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
             }
         }
 
+        RT_LAP(TM_FETCH);
         /* ================= GEN: jitter the direction, test the simple objects ============== */
         if (mode == M_GEN) {
             RT_STAT(ST_GEN);
@@ -501,6 +540,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
             mode = (HAS_MESH && a.num_meshes > 0) ? M_MESH : M_SHADE;
         }
 
+        RT_LAP(TM_GEN);
         if (HAS_MESH) {
             /* ================= MESH: find the next mesh whose root box the ray enters ======= */
             while (mode == M_MESH) {
@@ -522,6 +562,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                 RT_STAT(ST_MESH_START);
             }
 
+            RT_LAP(TM_MESH);
             /* ================= WORK: BVH traversal steps (src/objects.cu:487-532, :586-600) ====
              * Runs while enough lanes are traversing; lanes whose ray is finished go back to
              * shading as soon as the traversing group is small.  Visit order, push order and
@@ -529,8 +570,13 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
             for (;;) {
                 const int n_active = __popcll(__ballot(w_active));
                 if (n_active == 0) break;
-                const int n_ready = __popcll(__ballot(mode != M_WAIT && mode != M_DONE));
+                const int n_ready = __popcll(__ballot(mode != M_WAIT && mode != M_DONE && mode != M_IDLE));
                 if (n_ready > 0 && (n_active < a.work_threshold || n_ready >= a.ready_break)) break;
+#if defined(RT_COSTMAP) && RT_COSTMAP == 2
+                c_wsteps += 1;      /* wave-level macro steps this lane lived through */
+#endif
+                bool at_leaf = false, need_pop = false;
+                RT_LAP(TM_CTL);
                 if (w_active) {
                     RT_STAT(ST_WORK_ITER);
                     /* one macro step: descend to a leaf (or run out of children), test the
@@ -539,8 +585,8 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                      * ~30 % fewer wave instructions but ran slower: the extra ballots and
                      * branches lengthen each wave's serial instruction stream, and at the 4
                      * waves/SIMD an LDS-resident scene allows that latency is not hidden.) */
-                    bool at_leaf = (cur & RT_REF_LEAF) != 0u;
-                    bool need_pop = at_leaf;
+                    at_leaf = (cur & RT_REF_LEAF) != 0u;
+                    need_pop = at_leaf;
                     if (!at_leaf) {
                         /* The body is branch-free: the deferred sibling is ALWAYS written to the
                          * slot above the top of the stack (one 8-byte LDS store) and the stack
@@ -554,6 +600,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                         const int n_keep = (n_enter * a.descend_keep) >> 6;
                         for (;;) {
                             RT_STAT(ST_NODE);
+                            RT_COST(c_steps++);
                             const v4f *n = L.nodes + 4 * (int)(cur & RT_REF_NODE_MASK);
                             v4f q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
                             float ld, rdist;
@@ -581,12 +628,14 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                             if (__popcll(__ballot(1)) < n_keep) break;      /* wave-uniform */
                         }
                     }
+                    RT_LAP_SPLIT(TM_DESCEND)
                     if (at_leaf) {
                         /* leaf: strict <, first triangle wins ties (:596) */
                         const int start = (int)(cur & RT_REF_START_MASK);
                         const int count = (int)((cur >> RT_REF_COUNT_SHIFT) & RT_REF_COUNT_MAX);
                         for (int k = 0; k < count; k++) {
                             RT_STAT(ST_LEAF_TRI);
+                            RT_COST(c_steps++);
                             float t, u, v;
                             bool h = tri_test(L.tris, start + k, o, d, t, u, v);
                             if (h && t < w_best) { w_best = t; w_prim = start + k; }
@@ -594,6 +643,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                     }
                     /* pop: an entry is taken iff !(dist > best) (:501); through a collapsed chain
                      * iff dist < best (:517) */
+                    RT_LAP_SPLIT(TM_LEAF)
                     bool found = !need_pop;                 /* still descending: nothing to pop */
                     while (need_pop && sp > 0) {
                         RT_STAT(ST_POP);
@@ -614,6 +664,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                         mode = next_mesh >= a.num_meshes ? M_SHADE : M_MESH;
                     }
                 }
+                RT_LAP(TM_POP);
             }
         }
 
@@ -622,6 +673,12 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
 #ifdef RT_STATS
     for (int i = 0; i < ST_N; i++) {
         if (st_exec[i]) { atomicAdd(&a.stats[2 * i], (unsigned long long)st_exec[i]); atomicAdd(&a.stats[2 * i + 1], (unsigned long long)st_lanes[i]); }
+    }
+    RT_LAP(TM_CTL);
+    if (lane == 0) {
+        for (int i = 0; i < TM_N; i++) atomicAdd(&a.stats[24 + i], st_time[i]);
+        atomicAdd(&a.stats[24 + TM_N], wall_clock64() - st_wall0);      /* summed wave lifetimes, 100 MHz ticks */
+        atomicAdd(&a.stats[24 + TM_N + 1], 1ull);                        /* waves */
     }
 #endif
 }

@@ -15,7 +15,7 @@ out = torch.empty((H, W, 3), device="cuda:0")
 for _ in range(2):
     rt.render_device(ctx, scene, cam, rt.RenderData(spp, 8, True, sky), 12345, 0, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     ms = ctx.last_kernel_ms()
-buf = (C.c_uint64 * 24)()
+buf = (C.c_uint64 * 48)()
 rt.lib().rt_debug_read_stats(ctx._h, buf)
 names = ["ITER", "SHADE", "SHADE_HIT", "FETCH", "GEN", "MESH", "MESH_START", "WORK_ITER", "NODE", "LEAF_TRI", "POP", "DONE_MESH"]
 cost = {"ITER": 20, "SHADE": 30, "SHADE_HIT": 700, "GEN": 300, "MESH": 40, "WORK_ITER": 15, "NODE": 84, "LEAF_TRI": 95, "POP": 12}
