@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libraytracer_amd.so")
 SOURCES = [os.path.join(HERE, "csrc", f) for f in ("rt_kernel.hip", "rt_capi.cpp", "rt_host.cpp")]
-HEADERS = [os.path.join(HERE, "csrc", f) for f in ("rt_math.h", "rt_rng.h", "rt_device_scene.h", "rt_host.h")] + [
+HEADERS = [os.path.join(HERE, "csrc", f) for f in ("rt_math.h", "rt_rng.h", "rt_device_scene.h", "rt_pixel.h", "rt_host.h")] + [
     os.path.join(ROOT, "include", "rt_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-result", "-I" + os.path.join(ROOT, "include")]

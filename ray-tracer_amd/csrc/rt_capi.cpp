@@ -19,6 +19,7 @@
 #include "rt_host.h"
 
 extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t rt_launch_render_pool(const rt_kernel_args *args, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t rt_launch_eval(int op, const uint32_t *in, uint32_t *out, int n, hipStream_t stream);
 extern "C" hipError_t rt_launch_rgba8(const float *rgb, int n_pixels, uint8_t *out, hipStream_t stream);
 
@@ -42,9 +43,9 @@ struct rt_ctx {
     int work_threshold = 8;      /* lanes; RT_AMD_WORK_THRESHOLD overrides (tuning: tools/ab_threshold.py) */
     int descend_keep = 24;       /* RT_AMD_DESCEND_KEEP (0..64): 0 = run every descent to its end */
     int tile_scatter = 1;        /* RT_AMD_TILE_SCATTER=0: hand tiles out in raster order */
-    int max_waves = 64;          /* RT_AMD_MAX_WAVES, experiment */
-    int chunk_log2 = 6;          /* RT_AMD_CHUNK_LOG2 (2..6), experiment */
     int ready_break = 24;        /* lanes; RT_AMD_READY_BREAK overrides; 65 = never */
+    int use_pool = 0;            /* RT_AMD_POOL=1: mesh scenes through the workgroup ray pool (rt_render_pool_kernel); an experiment, slower */
+    int pool_fill = 16, pool_low = 16, pool_leaf_batch = 48;    /* RT_AMD_POOL_FILL / _LOW / _LEAF_BATCH */
 };
 
 struct rt_scene {
@@ -58,6 +59,7 @@ struct rt_scene {
     int scene_in_lds = 1;    /* 0: scene read from global memory (does not fit LDS) */
     uint32_t uid = 0;        /* distinguishes scenes in the tile-order cache (addresses get reused) */
     size_t lds_bytes = 0;
+    int pool = 0;            /* 1: rendered by the pooled kernel (threads / lds_bytes are its) */
 };
 
 namespace {
@@ -79,6 +81,17 @@ rt_status set_err(rt_ctx *ctx, rt_status code, const std::string &msg)
 {
     if (ctx) ctx->err = msg;
     return code;
+}
+
+/* the pooled kernel raises tile_counter[1] when one of its queue waits gave up (a bug, never a
+ * property of the input): the frame is then not to be trusted */
+rt_status check_kernel_flag(rt_ctx *ctx)
+{
+    uint32_t flag = 0;
+    hipError_t e = hipMemcpy(&flag, ctx->tile_counter + 1, 4, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return hip_fail(ctx, e, "reading kernel status");
+    if (flag) return set_err(ctx, RT_ERR_HIP, "Error from HIP (render kernel): traversal queue watchdog fired, frame incomplete");
+    return RT_OK;
 }
 
 }  // namespace
@@ -104,8 +117,10 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (const char *e = getenv("RT_AMD_DESCEND_KEEP")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->descend_keep = v; }
     if (const char *e = getenv("RT_AMD_TILE_SCATTER")) ctx->tile_scatter = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_HEAVY_FIRST")) ctx->heavy_first = atoi(e) != 0;
-    if (const char *e = getenv("RT_AMD_MAX_WAVES")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->max_waves = v; }
-    if (const char *e = getenv("RT_AMD_CHUNK_LOG2")) { int v = atoi(e); if (v >= 2 && v <= 6) ctx->chunk_log2 = v; }
+    if (const char *e = getenv("RT_AMD_POOL")) ctx->use_pool = atoi(e) != 0;
+    if (const char *e = getenv("RT_AMD_POOL_FILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->pool_fill = v; }
+    if (const char *e = getenv("RT_AMD_POOL_LOW")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->pool_low = v; }
+    if (const char *e = getenv("RT_AMD_POOL_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->pool_leaf_batch = v; }
     if (const char *e = getenv("RT_AMD_READY_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->ready_break = v; }
     if (hipMalloc((void **)&ctx->tile_counter, 1024) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
@@ -156,7 +171,24 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
             if (blob_bytes + per_thread * (size_t)nt <= RT_LDS_LIMIT) { s->threads = nt; s->lds_bytes = blob_bytes + per_thread * (size_t)nt; break; }
         }
     }
+    /* pooled kernel: 48-byte ray record + 2-byte stack levels per thread, two queues, control words */
+    const size_t pool_per_thread = 48 + (size_t)(s->flat.stack_entries + 1) * 2;
+    const size_t pool_fixed = 2 * 1024 * 4 + 64;
+    const bool pool_ok = ctx->use_pool && s->flat.has_mesh && s->flat.stack_entries <= 30 && s->flat.num_nodes < 65536;
+    if (pool_ok) {
+        s->threads = 0;
+        for (int nt : candidates) {
+            if (blob_bytes + pool_fixed + pool_per_thread * (size_t)nt <= RT_LDS_LIMIT) { s->threads = nt; s->lds_bytes = blob_bytes + pool_fixed + pool_per_thread * (size_t)nt; break; }
+        }
+        s->pool = 1;
+    }
     s->scene_in_lds = 1;
+    if (s->threads == 0 && s->pool) {
+        s->scene_in_lds = 0;
+        s->threads = 1024;
+        s->lds_bytes = pool_fixed + pool_per_thread * 1024;
+        if (s->lds_bytes > RT_LDS_LIMIT) { s->pool = 0; s->scene_in_lds = 1; }
+    }
     if (s->threads == 0) {
         /* larger than a CU's LDS: the kernel reads the scene from global memory (L2-resident),
          * LDS holds only the traversal stacks */
@@ -341,9 +373,9 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     a.stack_entries = scene->flat.stack_entries;
     a.work_threshold = ctx->work_threshold;
     a.ready_break = ctx->ready_break;
-    a.chunk_log2 = ctx->chunk_log2;
-    a.max_waves = ctx->max_waves;
-    if (ctx->chunk_log2 < 6) { a.num_tiles <<= (6 - ctx->chunk_log2); a.tile_order = nullptr; a.tile_stride = 1; }
+    a.pool_fill = ctx->pool_fill;
+    a.pool_low = ctx->pool_low;
+    a.pool_leaf_batch = ctx->pool_leaf_batch;
     a.descend_keep = ctx->descend_keep;
     a.tri_uv = scene->d_tri_uv;
     a.tex_data = scene->d_tex;
@@ -364,9 +396,12 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
         }
         int blocks = ctx->num_cus * blocks_per_cu;
         int needed = (a.num_tiles + waves_per_block - 1) / waves_per_block;
-        if (blocks > needed && ctx->max_waves >= 64) blocks = needed;
+        if (blocks > needed) blocks = needed;
         RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 512, stream), "clearing tile counter");
-        RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
+        if (scene->pool)
+            RT_HIP(ctx, rt_launch_render_pool(&a, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
+        else
+            RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream), "recording stop event");
     ctx->have_timing = true;
@@ -407,7 +442,7 @@ extern "C" rt_status rt_last_kernel_ms(rt_ctx *ctx, float *ms)
     if (!ctx->have_timing) return set_err(ctx, RT_ERR_INVALID, "no render has been launched yet");
     RT_HIP(ctx, hipEventSynchronize(ctx->ev_stop), "waiting for render kernel");
     RT_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop), "reading kernel time");
-    return RT_OK;
+    return check_kernel_flag(ctx);
 }
 
 extern "C" rt_status rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
@@ -430,6 +465,7 @@ extern "C" rt_status rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_came
     rt_status st = rt_render_device(ctx, scene, cam, rs, time_ms, *frame_num, nullptr, ctx->d_prev, ctx->d_out, nullptr);
     if (st != RT_OK) return st;
     RT_HIP(ctx, hipDeviceSynchronize(), "render kernel");
+    if ((st = check_kernel_flag(ctx)) != RT_OK) return st;
     RT_HIP(ctx, hipMemcpy(previous_render, ctx->d_out, bytes, hipMemcpyDeviceToHost), "copying frame to host");
     *frame_num += 1;                                   /* src/dispatch.cu:159 */
     RT_HIP(ctx, hipPeekAtLastError(), "final check after render");   /* src/dispatch.cu:161-162 */

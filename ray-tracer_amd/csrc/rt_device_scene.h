@@ -112,9 +112,10 @@ typedef struct {
     int32_t work_threshold;        /* run traversal steps while at least this many lanes traverse */
     int32_t descend_keep;          /* leave the descend loop when fewer than descend_keep/64 of its lanes remain */
     int32_t ready_break;           /* ... unless at least this many lanes are ready to shade / generate */
-    int32_t max_waves;             /* experiment: waves of a block beyond this many exit at once */
-    int32_t chunk_log2;            /* experiment: a ticket covers 2^chunk_log2 pixel ids (6 = one 8x8 tile); below 6 the wave
-                                      takes no further ticket until those pixels are finished */
+    /* pooled kernel */
+    int32_t pool_fill;             /* a box-test executor hands on / takes on rays once this many of its lanes are not stepping */
+    int32_t pool_low;              /* ... or at once, when fewer than this many are */
+    int32_t pool_leaf_batch;       /* triangle tests wait for this many posted rays (or more than box tests have) */
     const float *tri_uv;           /* 6 floats per triangle, or NULL */
     const float *tex_data;         /* IMAGE texture texels (rgb floats), or NULL */
     /* frame buffers */

@@ -35,100 +35,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "rt_device_scene.h"
-#include "rt_math.h"
-#include "rt_rng.h"
-
-#define RT_WAVE 64
-
-/* 16-byte vector for LDS / global accesses: a single ds_read_b128 / global_load_dwordx4 each
- * (a struct of four floats gets split into narrower loads by the optimiser) */
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-struct V3 { float x, y, z; };
-
-__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
-__device__ __forceinline__ V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
-/* src/utils.cu:130-136: (x*x' + y*y') + z*z' */
-__device__ __forceinline__ float dot(V3 a, V3 b) { float nx = a.x * b.x, ny = a.y * b.y, nz = a.z * b.z; return nx + ny + nz; }
-/* src/utils.cu:146-153 */
-__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-/* src/utils.cu:118-128: one reciprocal of the magnitude, three multiplies */
-__device__ __forceinline__ V3 normalised(V3 a)
-{
-    float m = a.x * a.x + a.y * a.y + a.z * a.z;
-    float inv = 1.0f / sqrtf(m);
-    return v3(a.x * inv, a.y * inv, a.z * inv);
-}
-__device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
-
-/* src/utils.cu:234-239 — Box-Muller cosine branch, theta drawn first.  rt_rng.h produces the
- * reference's (float)(r / 4294967295.0) and the binary64 products derived from it without the
- * binary64 divide, bit for bit (tests/test_rng_exhaustive.py covers all 2^32 inputs). */
-__device__ __forceinline__ float normal_num(uint32_t &state)
-{
-    float theta = rt_theta(rt_pcg_next(&state));
-    float rho = sqrtf(-2.0f * rt_logf(rt_u01(rt_pcg_next(&state))));
-    return rho * rt_cosf(theta);
-}
-
-struct Lds {
-    const v4f *nodes;
-    const v4f *tris;
-    const v4f *objs;
-    const v4f *meshes;
-    const v4f *objtab;   /* the object list (rt_object, 3 x 16 B each), read with wave-uniform addresses */
-    uint2 *stack;        /* [stack_entries + 1][NT] deferred sibling: (entry distance bits, reference) */
-};
-
-/* BoundingBox::ray_hits src/objects.cu:404-434.  fminf/fmaxf drop a NaN operand like CUDA's
- * min/max; the result only ever feeds comparisons, so the sign of a zero is irrelevant. */
-__device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
-                                         V3 o, V3 inv, float &tmin_out)
-{
-    float tmin = 0.0f, tmax = RT_INF_F;
-    float t1 = (bx0 - o.x) * inv.x, t2 = (bx1 - o.x) * inv.x;
-    tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
-    t1 = (by0 - o.y) * inv.y; t2 = (by1 - o.y) * inv.y;
-    tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
-    t1 = (bz0 - o.z) * inv.z; t2 = (bz1 - o.z) * inv.z;
-    tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
-    tmin_out = tmin;
-    return tmin < tmax && tmax > 0.0f;
-}
-
-/* Triangle::hit src/objects.cu:135-163 (Moller-Trumbore, two-sided, no early out) */
-__device__ __forceinline__ bool tri_test(const v4f *tris, int idx, V3 o, V3 d, float &t_out, float &u_out, float &v_out)
-{
-    v4f q0 = tris[3 * idx], q1 = tris[3 * idx + 1], q2 = tris[3 * idx + 2];
-    V3 p0 = v3(q0.x, q0.y, q0.z), s1 = v3(q0.w, q1.x, q1.y), s2 = v3(q1.z, q1.w, q2.x);
-    V3 p_vec = cross(d, s2);
-    float det = dot(s1, p_vec);
-    float inv_det = 1.0f / det;
-    V3 t_vec = o - p0;
-    float u = dot(t_vec, p_vec) * inv_det;
-    V3 q_vec = cross(t_vec, s1);
-    float v = dot(d, q_vec) * inv_det;
-    float w = 1.0f - u - v;
-    float dist = dot(s2, q_vec) * inv_det;
-    t_out = dist; u_out = u; v_out = v;
-    return dist > RT_EPS_F && u >= 0.0f && v >= 0.0f && w >= 0.0f;
-}
-
-/* Quad::hit src/objects.cu:223-236 — t1 if it hits, whatever t2's distance; else t2 */
-__device__ __forceinline__ bool quad_test(const v4f *tris, int first, V3 o, V3 d, float &t_out, int &prim_out)
-{
-    float t1, t2, u, v;
-    bool h1 = tri_test(tris, first, o, d, t1, u, v);
-    bool h2 = tri_test(tris, first + 1, o, d, t2, u, v);
-    t_out = h1 ? t1 : t2;
-    prim_out = h1 ? first : first + 1;
-    return h1 || h2;
-}
+#include "rt_pixel.h"
 
 /* Development instrumentation (-DRT_STATS, tools/stats_run.py): per code section, how many
  * times a wave executed it and with how many active lanes.  Compiled out of the product. */
@@ -151,8 +58,21 @@ enum { TM_CTL = 0, TM_SHADE = 1, TM_FETCH = 2, TM_GEN = 3, TM_MESH = 4, TM_DESCE
 #endif
 enum { ST_ITER = 0, ST_SHADE = 1, ST_SHADE_HIT = 2, ST_FETCH = 3, ST_GEN = 4, ST_MESH = 5, ST_MESH_START = 6, ST_WORK_ITER = 7, ST_NODE = 8, ST_LEAF_TRI = 9, ST_POP = 10, ST_DONE_MESH = 11, ST_N = 12 };
 
-/* lane states of the render loop */
-enum { M_FETCH = 0, M_GEN = 1, M_MESH = 2, M_WAIT = 3, M_SHADE = 4, M_DONE = 5, M_IDLE = 6 };
+#ifdef RT_STATS
+#define RT_STATS_FLUSH() do {                                                                              \
+    for (int i = 0; i < ST_N; i++) {                                                                          \
+        if (st_exec[i]) { atomicAdd(&a.stats[2 * i], (unsigned long long)st_exec[i]); atomicAdd(&a.stats[2 * i + 1], (unsigned long long)st_lanes[i]); } \
+    }                                                                                                         \
+    RT_LAP(TM_CTL);                                                                                           \
+    if (lane == 0) {                                                                                          \
+        for (int i = 0; i < TM_N; i++) atomicAdd(&a.stats[24 + i], st_time[i]);                               \
+        atomicAdd(&a.stats[24 + TM_N], wall_clock64() - st_wall0);      /* summed wave lifetimes, 100 MHz ticks */ \
+        atomicAdd(&a.stats[24 + TM_N + 1], 1ull);                        /* waves */                          \
+    }                                                                                                         \
+} while (0)
+#else
+#define RT_STATS_FLUSH() do { } while (0)
+#endif
 
 /* SCENE_LDS = false is the fallback for scenes larger than a CU's LDS: the same code reads the
  * scene sections from global memory (they stay L2 / Infinity-Cache resident) and only the
@@ -165,6 +85,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
     const int lane = tid & (RT_WAVE - 1);
 
     Lds L;
+    uint2 *stack;        /* [stack_entries + 1][NT] deferred sibling: (entry distance bits, reference) */
     if (SCENE_LDS) {
         /* stage the scene into LDS: coalesced 16-byte loads, one pass per workgroup */
         for (int i = tid; i < a.blob_f4; i += NT) lds_raw[i] = ((const v4f *)a.blob)[i];
@@ -173,7 +94,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
         L.objs = lds_raw + a.off_objlds;
         L.meshes = lds_raw + a.off_meshes;
         L.objtab = lds_raw + a.off_objtab;
-        L.stack = (uint2 *)(lds_raw + a.blob_f4);
+        stack = (uint2 *)(lds_raw + a.blob_f4);
     } else {
         const v4f *g = (const v4f *)a.blob;
         L.nodes = g + a.off_nodes;
@@ -181,44 +102,21 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
         L.objs = g + a.off_objlds;
         L.meshes = g + a.off_meshes;
         L.objtab = g + a.off_objtab;
-        L.stack = (uint2 *)lds_raw;
+        stack = (uint2 *)lds_raw;
     }
     __syncthreads();
-    if ((tid >> 6) >= a.max_waves) return;
 
-    const V3 cam_pos = v3(a.cam[0], a.cam[1], a.cam[2]);
-    const V3 tl = v3(a.cam[3], a.cam[4], a.cam[5]);
-    const V3 du = v3(a.cam[6], a.cam[7], a.cam[8]);
-    const V3 dv = v3(a.cam[9], a.cam[10], a.cam[11]);
-    const V3 sky = v3(a.sky[0], a.sky[1], a.sky[2]);
-    const int W = a.width, H = a.height;
-    const int spp = a.rays_per_pixel, limit = a.reflection_limit;
-    const int tiles_per_band = a.tiles_x * (a.band_rows >> 3);
-
-    /* ---- per-lane pixel state (registers) ---- */
-    int mode = M_FETCH;
-    uint32_t rng = 0;
-    V3 colour = v3(0.f, 0.f, 0.f), fin = colour, thr = colour, o = colour, d = colour, inv = colour, primary = colour;
-    int sample = 0, bounce = 0, px = 0, py = 0;
-    float cur_n = 1.0f;                  /* Ray::current_refractive_index src/ray.cu:56,144 */
-    float best_t = RT_INF_F;
-    int best_obj = -1, best_prim = -1, next_mesh = 0;
+    Frame f;
+    frame_init(f, a);
+    Px p;
+    px_init(p);
     /* ---- per-lane traversal state (registers + LDS stack) ---- */
     bool w_active = false;
     uint32_t cur = 0;
     int sp = 0, w_prim = -1, w_obj = -1;
     float w_best = RT_INF_F;
-    /* ---- wave-uniform pixel chunk: linear pixel ids [chunk_next, chunk_end) of one 8x8 tile ---- */
-    uint32_t chunk_next = 0, chunk_end = 0;
-    bool exhausted = false;
-#ifdef RT_COSTMAP
-    /* development build (tools/costmap.py): the frame holds, per pixel, (own traversal steps,
-     * start tick, end tick) of the 100 MHz wall clock instead of the colour */
-    unsigned c_steps = 0, c_t0 = 0, c_wsteps = 0;
-#define RT_COST(x) do { x; } while (0)
-#else
-#define RT_COST(x) do { } while (0)
-#endif
+    Chunk ch;
+    ch.next = 0; ch.end = 0; ch.exhausted = false;
 #ifdef RT_STATS
     unsigned st_exec[ST_N], st_lanes[ST_N];
     for (int i = 0; i < ST_N; i++) { st_exec[i] = 0; st_lanes[i] = 0; }
@@ -230,335 +128,37 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
     for (;;) {
         RT_STAT(ST_ITER);
         RT_LAP(TM_CTL);
-        /* ================= SHADE: the closest hit of this bounce is known ================== */
-        if (mode == M_SHADE) {
+        if (p.mode == M_SHADE) {
             RT_STAT(ST_SHADE);
-            bool end_sample;
-            if (best_obj < 0) {
-                /* src/raytracer.cu:76-80 */
-                fin = fin + sky * thr;
-                end_sample = true;
-            } else {
-                RT_STAT(ST_SHADE_HIT);
-                const v4f ma = L.objs[RT_OBJLDS_F4 * best_obj], mb = L.objs[RT_OBJLDS_F4 * best_obj + 1];
-                const uint32_t packed = __float_as_uint(mb.w);
-                const int mtype = (int)(packed & 3u);
-                /* hit point and normal: Ray::get_pos src/ray.cu:63-65; Sphere :66; Triangle :158 */
-                V3 P = d * best_t + o;
-                V3 N;
-                float tex_u = 0.f, tex_v = 0.f;
-                if (packed & 32u) {
-                    const v4f sc = L.objs[RT_OBJLDS_F4 * best_obj + 2];
-                    N = normalised(P - v3(sc.x, sc.y, sc.z));
-                    if (packed & 16u) {
-                        /* Sphere::assign_texture_coords src/objects.cu:82-97 (latitude / longitude) */
-                        const float PI = 3.141592653589793f;
-                        const float theta = rt_asinf((P.y - sc.y) / sc.w);
-                        const float phi = rt_acosf((P.x - sc.x) / sc.w);
-                        tex_u = (theta + PI / 2) / PI;
-                        const float v_ratio = (1 - phi / PI) / 2;
-                        const int behind = P.z > sc.z ? 1 : 0;
-                        const int mult = 1 - 2 * behind;
-                        tex_v = (float)(1 * behind) + (float)mult * v_ratio;
-                    }
-                } else {
-                    const v4f q2 = L.tris[3 * best_prim + 2];
-                    V3 n = v3(q2.y, q2.z, q2.w);
-                    N = (dot(n, d) > 0.0f) ? neg(n) : n;
-                    if (packed & 16u) {
-                        /* Triangle::assign_texture_coords src/objects.cu:160,196-199, called as (w,u,v) */
-                        float t, u, v;
-                        tri_test(L.tris, best_prim, o, d, t, u, v);
-                        float w = 1.0f - u - v;
-                        const float *uv = a.tri_uv + 6 * best_prim;
-                        tex_u = uv[0] * w + uv[2] * u + uv[4] * v;
-                        tex_v = uv[1] * w + uv[3] * u + uv[5] * v;
-                    }
-                }
-                /* update_ray src/raytracer.cu:49-64: REFRACTIVE goes through Ray::refract
-                 * (src/ray.cu:77-128, Snell + Schlick + total internal reflection), which falls
-                 * back to reflect(); everything else reflects */
-                bool do_reflect = true;
-                V3 refr_dir = v3(0.f, 0.f, 0.f);
-                if (mtype == RT_DEV_MAT_REFRACTIVE) {
-                    const float mat_n = L.objs[RT_OBJLDS_F4 * best_obj + 3].x;
-                    float n1, n2;
-                    V3 rn;
-                    if (dot(N, d) > 0.0f) { n1 = mat_n; n2 = cur_n; rn = N; }        /* leaving the object */
-                    else                  { n1 = cur_n; n2 = mat_n; rn = neg(N); }   /* entering */
-                    cur_n = n2;
-                    /* min(float, double) is CUDA's double overload; acos / asin of doubles */
-                    const float theta1 = (float)rt_acos(fmin((double)dot(d, rn), 1.0));
-                    const float theta2 = (float)rt_asin(fmin((double)(n1 * rt_sinf(theta1) / n2), 1.0));
-                    const float critical_angle = rt_asinf(n2 / n1);
-                    /* get_reflection_coeff :188-196: pow(float, int) is the double pow */
-                    const float sqrt_r0 = (n1 - n2) / (n1 + n2);
-                    const float r0 = sqrt_r0 * sqrt_r0;
-                    const float cos_theta = rt_cosf(theta1);
-                    const float reflection_coeff = (float)((double)r0 + (double)(1.0f - r0) * rt_pow5((double)(1.0f - cos_theta)));
-                    do_reflect = theta1 > critical_angle;
-                    if (!do_reflect) do_reflect = reflection_coeff > rt_u01(rt_pcg_next(&rng));   /* `||` short-circuits */
-                    if (!do_reflect) {
-                        V3 perp = v3(0.f, 0.f, 0.f);
-                        if (theta1 != 0.0f) perp = (d - rn * rt_cosf(theta1)) / rt_sinf(theta1);
-                        refr_dir = normalised(rn * rt_cosf(theta2) + perp * rt_sinf(theta2));
-                    }
-                }
-                if (do_reflect) {
-                    /* Ray::reflect src/ray.cu:67-75 with diffuse_reflect :157-170,
-                     * true_lambertian_reflect :172-178, perfect_reflect :180-186, lerp :32-34 */
-                    float gx = normal_num(rng);
-                    float gy = normal_num(rng);
-                    float gz = normal_num(rng);
-                    V3 rv = v3(gx, gy, gz);
-                    if (dot(rv, N) < 0.0f) rv = neg(rv);
-                    rv = normalised(rv);
-                    V3 diffuse_dir = normalised(N + rv);
-                    float dn = dot(d, N);
-                    V3 specular_dir = normalised(d - (N * 2.0f) * dn);
-                    d = normalised(diffuse_dir + (specular_dir - diffuse_dir) * ma.w);
-                } else {
-                    d = refr_dir;
-                }
-                o = P;
-
-                /* src/raytracer.cu:86-90 */
-                if (mtype == RT_DEV_MAT_EMISSIVE) {
-                    fin = fin + v3(mb.x, mb.y, mb.z) * thr;
-                } else {
-                    V3 tc;
-                    const int tex = (int)((packed >> 2) & 3u);
-                    if (tex == 0) {
-                        tc = v3(ma.x, ma.y, ma.z);
-                    } else if (tex == 1) {
-                        tc = v3(tex_u, tex_v, 0.f);                              /* gradient src/material.cu:80-82 */
-                    } else if (tex == 3) {
-                        /* image src/material.cu:119-124: nearest texel; an out-of-range index is clamped */
-                        const int iw = (int)__float_as_uint(ma.x), ih = (int)__float_as_uint(ma.y);
-                        const int uc = (int)((float)(iw - 1) * tex_u), vc = (int)((float)(ih - 1) * tex_v);
-                        int idx = vc * iw + uc;
-                        idx = idx < 0 ? 0 : (idx > iw * ih - 1 ? iw * ih - 1 : idx);
-                        const float *tx = a.tex_data + (size_t)__float_as_uint(ma.z) + 3 * (size_t)idx;
-                        tc = v3(tx[0], tx[1], tx[2]);
-                    } else {
-                        const int nsq = (int)(packed >> 8);                      /* checkerboard :90-99 */
-                        int uc = (int)(tex_u * (float)nsq), vc = (int)(tex_v * (float)nsq);
-                        tc = ((uc + vc) % 2 == 0) ? v3(ma.x, ma.y, ma.z) : v3(mb.x, mb.y, mb.z);
-                    }
-                    thr = thr * tc;
-                }
-                bounce++;
-                end_sample = bounce >= limit;
-            }
-            mode = M_GEN;
-            if (end_sample) {
-                /* src/raytracer.cu:102-105: the next sample restarts from a copy of the primary ray */
-                colour = colour + fin;
-                sample++;
-                fin = v3(0.f, 0.f, 0.f); thr = v3(1.f, 1.f, 1.f);
-                o = cam_pos; d = primary; bounce = 0; cur_n = 1.0f;
-                if (sample >= spp) {
-                    /* src/raytracer.cu:107-112 and :133-135 */
-                    const int array_index = (py * W + px) * 3;
-                    V3 c = colour / (float)spp;
-                    V3 previous = v3(0.f, 0.f, 0.f);
-                    if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
-                    V3 previous_sum = previous * (float)a.frame_num;
-                    V3 res = (c + previous_sum) / (float)(a.frame_num + 1);
-                    int out_row = py;
-                    if (a.compact) {
-                        const int band = py / a.band_rows;
-                        out_row = ((band - a.band_first) / a.band_stride) * a.band_rows + (py - band * a.band_rows);
-                    }
-                    float *dst = a.out + ((size_t)out_row * (size_t)W + (size_t)px) * 3;
-#ifdef RT_COSTMAP
-                    res = v3(__uint_as_float(RT_COSTMAP == 2 ? c_wsteps : c_steps), __uint_as_float(c_t0), __uint_as_float((unsigned)wall_clock64()));
-#endif
-                    dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-                    mode = M_FETCH;
-                }
-            }
+            px_shade(p, a, f, L);
         }
-
         RT_LAP(TM_SHADE);
-        /* ================= FETCH: lanes without a pixel take the next ones ==================
-         * Linear pixel ids are tile-major (64 per 8x8 tile), tiles come from a global counter;
-         * a wave asks for one tile at a time and hands its ids out to whichever lanes are free. */
-        {
-            if (a.chunk_log2 < 6) {
-                /* experiment: lanes left over by a small ticket sit idle until the wave's pixels are done */
-                const bool busy = __ballot(mode == M_GEN || mode == M_MESH || mode == M_WAIT || mode == M_SHADE) != 0ull;
-                if (busy && mode == M_FETCH) mode = M_IDLE;
-                if (!busy && mode == M_IDLE) mode = M_FETCH;
-            }
-            const bool want = mode == M_FETCH;
-            const unsigned long long mask = __ballot(want);
-            if (mask) {
-                const int need = __popcll(mask);
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                int taken = 0;
-                int my_id = -1;
-                bool got_ticket = false;
-                for (;;) {
-                    const int avail = (int)(chunk_end - chunk_next);
-                    const int take = avail < need - taken ? avail : need - taken;
-                    if (want && rank >= taken && rank < taken + take) my_id = (int)chunk_next + (rank - taken);
-                    chunk_next += (uint32_t)take;
-                    taken += take;
-                    if (taken == need || exhausted || (a.chunk_log2 < 6 && got_ticket)) break;
-                    uint32_t t = 0;
-                    if (lane == 0) t = atomicAdd(a.tile_counter, 1u);
-                    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                    if (t >= (uint32_t)a.num_tiles) { exhausted = true; break; }
-                    /* ticket -> tile through a permutation.  A pixel's samples are sequential, so
-                     * the frame cannot finish before its most expensive tile does; the host
-                     * therefore lists the tiles whose centre ray enters a mesh box first
-                     * (longest-job-first), each class scattered by a stride coprime to the tile
-                     * count so that neighbouring (equally expensive) tiles do not land on the
-                     * waves of one CU.  Any order gives the same image. */
-                    t = a.tile_order ? a.tile_order[t]
-                                     : (uint32_t)(((unsigned long long)t * (unsigned long long)a.tile_stride) % (unsigned long long)a.num_tiles);
-                    chunk_next = t << a.chunk_log2;
-                    chunk_end = chunk_next + (1u << a.chunk_log2);
-                    got_ticket = true;
-                }
-                if (want) {
-                    if (my_id < 0) {
-                        if (exhausted) mode = M_DONE;
-                    } else {
-                        const int tile = my_id >> 6, within = my_id & 63;
-                        const int band_local = tile / tiles_per_band;
-                        const int in_band = tile - band_local * tiles_per_band;
-                        const int band = a.band_first + band_local * a.band_stride;
-                        const int ty = in_band / a.tiles_x, tx = in_band - ty * a.tiles_x;
-                        px = tx * 8 + (within & 7);
-                        py = band * a.band_rows + ty * 8 + (within >> 3);
-                        if (px < W && py < H) {
-                            /* src/raytracer.cu:123-127; Ray::set_direction_origin src/ray.cu:147-155,
-                             * cam_pixel_to_world src/camera.cu:24-29 */
-                            const int array_index = (py * W + px) * 3;
-                            rng = (uint32_t)array_index * 3145739u + a.seed_time;
-                            RT_COST(c_steps = 0; c_wsteps = 0; c_t0 = (unsigned)wall_clock64());
-                            V3 plane_point = du * (float)px + dv * (float)py;
-                            primary = normalised((tl + plane_point) - cam_pos);
-                            colour = v3(0.f, 0.f, 0.f);
-                            fin = v3(0.f, 0.f, 0.f); thr = v3(1.f, 1.f, 1.f);
-                            o = cam_pos; d = primary;
-                            bounce = 0; cur_n = 1.0f;
-                            /* a zero bounce limit traces nothing: every sample is (0,0,0) */
-                            sample = limit > 0 ? 0 : spp;
-                            if (sample >= spp) {
-                                const float q = 0.0f / (float)spp;               /* NaN for spp == 0, like the reference */
-                                V3 previous = v3(0.f, 0.f, 0.f);
-                                if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
-                                V3 res = (v3(q, q, q) + previous * (float)a.frame_num) / (float)(a.frame_num + 1);
-                                int out_row = py;
-                                if (a.compact) out_row = band_local * a.band_rows + (py - band * a.band_rows);
-                                float *dst = a.out + ((size_t)out_row * (size_t)W + (size_t)px) * 3;
-                                dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-                                /* stays in M_FETCH: takes another pixel next time round */
-                            } else {
-                                mode = M_GEN;
-                            }
-                        }
-                        /* a pixel outside the image (ragged edge tile): stay in M_FETCH */
-                    }
-                }
-            }
-        }
-
+        px_fetch(p, ch, a, f, lane);
         RT_LAP(TM_FETCH);
-        /* ================= GEN: jitter the direction, test the simple objects ============== */
-        if (mode == M_GEN) {
+        if (p.mode == M_GEN) {
             RT_STAT(ST_GEN);
-            /* Ray::apply_antialias src/ray.cu:130-142 */
-            if (a.antialias) {
-                V3 off;
-                off.x = rt_jitter(rt_pcg_next(&rng));
-                off.y = rt_jitter(rt_pcg_next(&rng));
-                off.z = rt_jitter(rt_pcg_next(&rng));
-                d = normalised(d + off);
-            }
-            if (HAS_MESH) inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   /* src/ray.cu:198-202 */
-
-            /* get_ray_collision src/raytracer.cu:24-46 over the non-mesh objects, in list order
-             * (`<=`: the later object wins ties, :36; the precision_error term is a no-op for
-             * accepted hits).  Meshes are merged afterwards with the same
-             * rule made explicit: smaller distance, or equal distance and larger list index. */
-            best_t = RT_INF_F; best_obj = -1; best_prim = -1;
-            for (int i = 0; i < a.num_objects; i++) {
-                /* rt_object from LDS: every lane reads the same address (broadcast) */
-                const v4f ob0 = L.objtab[3 * i], ob1 = L.objtab[3 * i + 1], ob2 = L.objtab[3 * i + 2];
-                rt_object ob;
-                ob.type = (int32_t)__float_as_uint(ob0.x); ob.prim_start = (int32_t)__float_as_uint(ob0.y);
-                ob.need_uv = (int32_t)__float_as_uint(ob0.z); ob.root_ref = __float_as_uint(ob0.w);
-                ob.v[0] = ob1.x; ob.v[1] = ob1.y; ob.v[2] = ob1.z; ob.v[3] = ob1.w;
-                ob.v[4] = ob2.x; ob.v[5] = ob2.y; ob.v[6] = ob2.z; ob.v[7] = ob2.w;
-                bool hit = false;
-                float t = RT_INF_F;
-                int prim = -1;
-                switch (ob.type) {
-                    case RT_OBJ_SPHERE: {   /* Sphere::hit src/objects.cu:40-79: near root, > 1e-6 */
-                        V3 cq = v3(ob.v[0], ob.v[1], ob.v[2]) - o;
-                        float qa = dot(d, d);
-                        float qb = dot(d, cq) * (-2.0f);
-                        float qc = dot(cq, cq) - ob.v[3] * ob.v[3];
-                        float disc = qb * qb - 4.0f * qa * qc;
-                        if (disc >= 0.0f) {
-                            float dist = (-qb - sqrtf(disc)) / (2.0f * qa);
-                            if (dist > RT_EPS_F) { hit = true; t = dist; }
-                        }
-                        break;
-                    }
-                    case RT_OBJ_TRIANGLE: {
-                        float u, v;
-                        hit = tri_test(L.tris, ob.prim_start, o, d, t, u, v);
-                        prim = ob.prim_start;
-                        break;
-                    }
-                    case RT_OBJ_ONE_WAY_QUAD:   /* src/objects.cu:273-280 */
-                        if (dot(d, v3(ob.v[0], ob.v[1], ob.v[2])) < 0.0f) break;
-                        /* fall through */
-                    case RT_OBJ_QUAD:
-                        hit = quad_test(L.tris, ob.prim_start, o, d, t, prim);
-                        break;
-                    case RT_OBJ_CUBOID: {       /* src/objects.cu:305-322: strict <, first face wins ties */
-                        float cb = RT_INF_F;
-                        for (int f = 0; f < 6; f++) {
-                            float ft; int fp;
-                            bool fh = quad_test(L.tris, ob.prim_start + 2 * f, o, d, ft, fp);
-                            if (fh && ft < cb) { cb = ft; prim = fp; hit = true; }
-                        }
-                        t = cb;
-                        break;
-                    }
-                    default: break;             /* RT_OBJ_MESH: below */
-                }
-                if (hit && t <= best_t) { best_t = t; best_obj = i; best_prim = prim; }
-            }
-            next_mesh = 0;
-            mode = (HAS_MESH && a.num_meshes > 0) ? M_MESH : M_SHADE;
+            px_gen<HAS_MESH>(p, a, L);
         }
-
         RT_LAP(TM_GEN);
+
         if (HAS_MESH) {
             /* ================= MESH: find the next mesh whose root box the ray enters ======= */
-            while (mode == M_MESH) {
+            while (p.mode == M_MESH) {
                 RT_STAT(ST_MESH);
-                if (next_mesh >= a.num_meshes) { mode = M_SHADE; break; }
-                const v4f m0 = L.meshes[2 * next_mesh], m1 = L.meshes[2 * next_mesh + 1];
-                next_mesh++;
+                if (p.next_mesh >= a.num_meshes) { p.mode = M_SHADE; break; }
+                const v4f m0 = L.meshes[2 * p.next_mesh], m1 = L.meshes[2 * p.next_mesh + 1];
+                p.next_mesh++;
                 /* a NaN direction (Box-Muller on a zero draw) fails every
                  * triangle test: the mesh cannot be hit, no need to walk it */
-                if (d.x != d.x || d.y != d.y || d.z != d.z) continue;
+                if (p.d.x != p.d.x || p.d.y != p.d.y || p.d.z != p.d.z) continue;
                 /* the root is pushed unconditionally and tested when popped (src/objects.cu:494-501) */
                 const uint32_t root_ref = __float_as_uint(m1.z);
                 float rd;
-                const bool rh = box_test(m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, o, inv, rd);
+                const bool rh = box_test(m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, p.o, p.inv, rd);
                 if (!rh || rd > RT_INF_F || ((root_ref & RT_REF_CHAIN) && !(rd < RT_INF_F))) continue;
                 cur = root_ref; sp = 0; w_best = RT_INF_F; w_prim = -1; w_obj = (int)__float_as_uint(m1.w);
                 w_active = true;
-                mode = M_WAIT;
+                p.mode = M_WAIT;
                 RT_STAT(ST_MESH_START);
             }
 
@@ -567,24 +167,21 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
              * Runs while enough lanes are traversing; lanes whose ray is finished go back to
              * shading as soon as the traversing group is small.  Visit order, push order and
              * every comparison are the reference's. */
+            const V3 o = p.o, d = p.d, inv = p.inv;
             for (;;) {
                 const int n_active = __popcll(__ballot(w_active));
                 if (n_active == 0) break;
-                const int n_ready = __popcll(__ballot(mode != M_WAIT && mode != M_DONE && mode != M_IDLE));
+                const int n_ready = __popcll(__ballot(p.mode != M_WAIT && p.mode != M_DONE));
                 if (n_ready > 0 && (n_active < a.work_threshold || n_ready >= a.ready_break)) break;
 #if defined(RT_COSTMAP) && RT_COSTMAP == 2
-                c_wsteps += 1;      /* wave-level macro steps this lane lived through */
+                p.c_wsteps += 1;      /* wave-level macro steps this lane lived through */
 #endif
                 bool at_leaf = false, need_pop = false;
                 RT_LAP(TM_CTL);
                 if (w_active) {
                     RT_STAT(ST_WORK_ITER);
                     /* one macro step: descend to a leaf (or run out of children), test the
-                     * leaf's triangles, pop the next deferred sibling.  (A variant that
-                     * schedules node steps and single-triangle steps by lane majority issued
-                     * ~30 % fewer wave instructions but ran slower: the extra ballots and
-                     * branches lengthen each wave's serial instruction stream, and at the 4
-                     * waves/SIMD an LDS-resident scene allows that latency is not hidden.) */
+                     * leaf's triangles, pop the next deferred sibling. */
                     at_leaf = (cur & RT_REF_LEAF) != 0u;
                     need_pop = at_leaf;
                     if (!at_leaf) {
@@ -600,7 +197,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                         const int n_keep = (n_enter * a.descend_keep) >> 6;
                         for (;;) {
                             RT_STAT(ST_NODE);
-                            RT_COST(c_steps++);
+                            RT_COST(p.c_steps++);
                             const v4f *n = L.nodes + 4 * (int)(cur & RT_REF_NODE_MASK);
                             v4f q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
                             float ld, rdist;
@@ -618,7 +215,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                             const bool entered = l_push || r_push;
                             const uint32_t deferred_ref = l_first ? lref : rref;
                             const float deferred_d = l_first ? ld : rdist;
-                            L.stack[sp * NT + tid] = make_uint2(__float_as_uint(deferred_d), deferred_ref);
+                            stack[sp * NT + tid] = make_uint2(__float_as_uint(deferred_d), deferred_ref);
                             sp += both ? 1 : 0;
                             const uint32_t next = both ? (l_first ? rref : lref) : (l_push ? lref : rref);
                             cur = entered ? next : cur;
@@ -635,7 +232,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                         const int count = (int)((cur >> RT_REF_COUNT_SHIFT) & RT_REF_COUNT_MAX);
                         for (int k = 0; k < count; k++) {
                             RT_STAT(ST_LEAF_TRI);
-                            RT_COST(c_steps++);
+                            RT_COST(p.c_steps++);
                             float t, u, v;
                             bool h = tri_test(L.tris, start + k, o, d, t, u, v);
                             if (h && t < w_best) { w_best = t; w_prim = start + k; }
@@ -648,7 +245,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                     while (need_pop && sp > 0) {
                         RT_STAT(ST_POP);
                         sp--;
-                        const uint2 e = L.stack[sp * NT + tid];
+                        const uint2 e = stack[sp * NT + tid];
                         const float dd = __uint_as_float(e.x);
                         const uint32_t rr = e.y;
                         const bool take = (rr & RT_REF_CHAIN) ? (dd < w_best) : !(dd > w_best);
@@ -657,30 +254,405 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                     if (!found) {
                         RT_STAT(ST_DONE_MESH);
                         /* this mesh is done: merge (smaller distance, or equal and later in the list) */
-                        if (w_prim >= 0 && (w_best < best_t || (w_best == best_t && w_obj > best_obj))) {
-                            best_t = w_best; best_obj = w_obj; best_prim = w_prim;
+                        if (w_prim >= 0 && (w_best < p.best_t || (w_best == p.best_t && w_obj > p.best_obj))) {
+                            p.best_t = w_best; p.best_obj = w_obj; p.best_prim = w_prim;
                         }
                         w_active = false;
-                        mode = next_mesh >= a.num_meshes ? M_SHADE : M_MESH;
+                        p.mode = p.next_mesh >= a.num_meshes ? M_SHADE : M_MESH;
                     }
                 }
                 RT_LAP(TM_POP);
             }
         }
 
-        if (__ballot(mode != M_DONE) == 0ull) break;
+        if (__ballot(p.mode != M_DONE) == 0ull) break;
     }
-#ifdef RT_STATS
-    for (int i = 0; i < ST_N; i++) {
-        if (st_exec[i]) { atomicAdd(&a.stats[2 * i], (unsigned long long)st_exec[i]); atomicAdd(&a.stats[2 * i + 1], (unsigned long long)st_lanes[i]); }
+    RT_STATS_FLUSH();
+}
+
+/* =============================================================================================
+ * The pooled kernel (mesh scenes): pixels stay with their lanes, RAYS do not.
+ *
+ * Measured on the kernel above (tools/costmap.py, tools/wave_probe.py): a wave that owns 64
+ * expensive pixels executes ~4x the traversal steps any one of its lanes needs (at every step
+ * only the lanes in the same phase - box tests or triangle tests - take part: ~19 and ~10 of 64),
+ * and a frame is as long as its slowest wave.  Here a lane that needs a mesh traversal writes
+ * its ray to a record in LDS (slot = thread id) and posts the slot on a queue; ANY wave of the
+ * workgroup that has nothing better to do takes up to 64 posted rays of ONE phase and steps them:
+ *
+ *   node queue -> box-test executor: descends / pops until a ray reaches a leaf (posted on the
+ *                 leaf queue) or runs out of stack (finished: the owner lane is told);
+ *   leaf queue -> triangle-test executor: tests the leaf's triangles, posts the ray back.
+ *
+ * So box tests run with (nearly) full waves of rays that all need a box test, likewise triangle
+ * tests, the 16 waves of a workgroup share the rays of its most expensive pixels, and waves whose
+ * own pixels are finished keep executing for the others until the workgroup is done.
+ *
+ * The traversal is still the reference's (src/objects.cu:487-532): same visit order, same push
+ * order, same comparisons.  Two representation changes make a ray small enough to park
+ * (48 bytes + 2 bytes per stack level): the stack holds only the index of the node whose second
+ * child was deferred, and a pop re-derives that child's entry distance by running the parent's
+ * two box tests again - the same operations on the same operands, hence the same bits (and the
+ * same test the reference itself repeats when it pops, :499-501).
+ *
+ * Queue protocol (LDS, workgroup scope): head / tail counters are monotonic; a producer reserves
+ * positions with one atomic add on tail, waits for each position to be EMPTY, then stores the
+ * slot id with release semantics; a consumer reserves [head, head + n) with a compare-and-swap
+ * bounded by tail, waits for each position to be filled, takes the id and stores EMPTY.  Nobody
+ * waits on anything but another wave's few-instruction critical section.
+ * ============================================================================================= */
+#define RT_POOL_DONE 0xffffffffu        /* record.cur once the traversal is finished */
+#define RT_POOL_EMPTY 0xffffffffu       /* a free queue position */
+#define RT_POOL_QCAP 1024u              /* queue capacity (power of two, >= threads per workgroup) */
+#define RT_META_POP 0x80000000u         /* record.meta: the ray must pop before it goes on */
+#define RT_META_SP_SHIFT 24             /* ... bits 28..24 stack pointer, bits 23..0 best triangle + 1 */
+#define RT_META_PRIM_MASK 0x00ffffffu
+#define RT_POOL_SPIN_LIMIT (1 << 24)
+enum { E_FREE = 0, E_NODE = 1, E_POP = 2, E_PARK_LEAF = 3, E_PARK_DONE = 4 };
+/* control words */
+enum { C_NODE_HEAD = 0, C_NODE_TAIL = 1, C_LEAF_HEAD = 2, C_LEAF_TAIL = 3, C_LIVE = 4, C_ABORT = 5, C_WORDS = 16 };
+
+#define RT_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define RT_ST(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define RT_ST_REL(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP)
+#define RT_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
+
+__device__ __forceinline__ int rt_rank(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+/* posts `slot` for every lane with doit set (one reservation per wave) */
+__device__ __forceinline__ void pool_push(uint32_t *tail, uint32_t *items, bool doit, uint32_t slot, uint32_t *abort_flag)
+{
+    if (doit) {
+        const unsigned long long m = __ballot(1);
+        const int rank = rt_rank(m);
+        uint32_t base = 0;
+        if (rank == 0) base = __hip_atomic_fetch_add(tail, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        uint32_t *it = items + ((base + (uint32_t)rank) & (RT_POOL_QCAP - 1u));
+        int spin = 0;
+        while (RT_LD(it) != RT_POOL_EMPTY) {
+            if (++spin > RT_POOL_SPIN_LIMIT) { RT_ST(abort_flag, 1u); break; }
+        }
+        RT_ST_REL(it, slot);
     }
-    RT_LAP(TM_CTL);
+}
+
+/* the whole wave calls; lanes with `want` set receive a posted slot id, or -1 */
+__device__ __forceinline__ int pool_grab(uint32_t *head_tail, uint32_t *items, bool want, int lane, uint32_t *abort_flag)
+{
+    const unsigned long long m = __ballot(want);
+    const int n_want = __popcll(m);
+    if (n_want == 0) return -1;
+    uint32_t h = 0;
+    int n = 0;
     if (lane == 0) {
-        for (int i = 0; i < TM_N; i++) atomicAdd(&a.stats[24 + i], st_time[i]);
-        atomicAdd(&a.stats[24 + TM_N], wall_clock64() - st_wall0);      /* summed wave lifetimes, 100 MHz ticks */
-        atomicAdd(&a.stats[24 + TM_N + 1], 1ull);                        /* waves */
+        for (;;) {
+            h = RT_LD(head_tail);
+            const uint32_t t = RT_LD(head_tail + 1);
+            const int avail = (int)(t - h);
+            n = avail < n_want ? avail : n_want;
+            if (n <= 0) { n = 0; break; }
+            uint32_t expected = h;
+            if (__hip_atomic_compare_exchange_strong(head_tail, &expected, h + (uint32_t)n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        }
     }
+    h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+    n = __builtin_amdgcn_readfirstlane(n);
+    int slot = -1;
+    const int rank = rt_rank(m);
+    if (want && rank < n) {
+        uint32_t *it = items + ((h + (uint32_t)rank) & (RT_POOL_QCAP - 1u));
+        uint32_t v;
+        int spin = 0;
+        while ((v = RT_LD(it)) == RT_POOL_EMPTY) {
+            if (++spin > RT_POOL_SPIN_LIMIT) { RT_ST(abort_flag, 1u); v = 0u; break; }
+        }
+        RT_ST(it, RT_POOL_EMPTY);
+        slot = (int)v;
+    }
+    RT_ACQUIRE();
+    return slot;
+}
+
+template <int NT, bool SCENE_LDS>
+__global__ __launch_bounds__(NT) void rt_render_pool_kernel(const rt_kernel_args a)
+{
+    extern __shared__ v4f lds_raw[];
+    const int tid = threadIdx.x;
+    const int lane = tid & (RT_WAVE - 1);
+
+    Lds L;
+    v4f *dyn;
+    if (SCENE_LDS) {
+        for (int i = tid; i < a.blob_f4; i += NT) lds_raw[i] = ((const v4f *)a.blob)[i];
+        L.nodes = lds_raw + a.off_nodes;
+        L.tris = lds_raw + a.off_tris;
+        L.objs = lds_raw + a.off_objlds;
+        L.meshes = lds_raw + a.off_meshes;
+        L.objtab = lds_raw + a.off_objtab;
+        dyn = lds_raw + a.blob_f4;
+    } else {
+        const v4f *g = (const v4f *)a.blob;
+        L.nodes = g + a.off_nodes;
+        L.tris = g + a.off_tris;
+        L.objs = g + a.off_objlds;
+        L.meshes = g + a.off_meshes;
+        L.objtab = g + a.off_objtab;
+        dyn = lds_raw;
+    }
+    /* ray records, one per thread: q0 = (origin, best distance) q1 = (direction, current reference)
+     * q2 = (1/direction, meta) */
+    v4f *rq0 = dyn, *rq1 = dyn + NT, *rq2 = dyn + 2 * NT;
+    uint32_t *node_q = (uint32_t *)(dyn + 3 * NT);
+    uint32_t *leaf_q = node_q + RT_POOL_QCAP;
+    uint32_t *ctl = leaf_q + RT_POOL_QCAP;
+    uint16_t *stack = (uint16_t *)(ctl + C_WORDS);       /* [stack_entries + 1][NT] parent node of the deferred child */
+    for (int i = tid; i < (int)RT_POOL_QCAP; i += NT) { node_q[i] = RT_POOL_EMPTY; leaf_q[i] = RT_POOL_EMPTY; }
+    if (tid < C_WORDS) ctl[tid] = tid == C_LIVE ? (uint32_t)(NT / RT_WAVE) : 0u;
+    __syncthreads();
+#define REC_BEST(slot) (((float *)(rq0 + (slot))) + 3)
+#define REC_CUR(slot) (((uint32_t *)(rq1 + (slot))) + 3)
+#define REC_META(slot) (((uint32_t *)(rq2 + (slot))) + 3)
+
+    Frame f;
+    frame_init(f, a);
+    Px p;
+    px_init(p);
+    int w_obj = -1;             /* object index of the mesh this lane's ray is in */
+    bool retired = false;       /* wave-uniform: every pixel of this wave is finished */
+    Chunk ch;
+    ch.next = 0; ch.end = 0; ch.exhausted = false;
+#ifdef RT_STATS
+    unsigned st_exec[ST_N], st_lanes[ST_N];
+    for (int i = 0; i < ST_N; i++) { st_exec[i] = 0; st_lanes[i] = 0; }
+    unsigned long long st_time[TM_N], st_last = __builtin_readcyclecounter();
+    const unsigned long long st_wall0 = wall_clock64();
+    for (int i = 0; i < TM_N; i++) st_time[i] = 0;
 #endif
+    unsigned long long idle_since = 0;
+
+    for (;;) {
+        RT_STAT(ST_ITER);
+        /* ---- traversals of my lanes that have finished: merge (smaller distance, or equal and
+         * later in the object list, src/raytracer.cu:36) */
+        if (p.mode == M_WAIT && RT_LD(REC_CUR(tid)) == RT_POOL_DONE) {
+            RT_ACQUIRE();
+            const float w_best = *REC_BEST(tid);
+            const int w_prim = (int)(*REC_META(tid) & RT_META_PRIM_MASK) - 1;
+            if (w_prim >= 0 && (w_best < p.best_t || (w_best == p.best_t && w_obj > p.best_obj))) {
+                p.best_t = w_best; p.best_obj = w_obj; p.best_prim = w_prim;
+            }
+            p.mode = p.next_mesh >= a.num_meshes ? M_SHADE : M_MESH;
+        }
+        const int n_live = __popcll(__ballot(p.mode != M_DONE));
+        int n_ready = __popcll(__ballot(p.mode == M_SHADE || p.mode == M_MESH || p.mode == M_GEN || p.mode == M_FETCH));
+        const int half_live = (n_live + 1) >> 1;
+        const int thr = a.ready_break < half_live ? a.ready_break : (half_live > 0 ? half_live : 1);
+        int n_node = __builtin_amdgcn_readfirstlane((int)(RT_LD(ctl + C_NODE_TAIL) - RT_LD(ctl + C_NODE_HEAD)));
+        int n_leaf = __builtin_amdgcn_readfirstlane((int)(RT_LD(ctl + C_LEAF_TAIL) - RT_LD(ctl + C_LEAF_HEAD)));
+        RT_LAP(TM_CTL);
+
+        /* ---- the pixels' own work, once enough lanes want it (or there is nothing else to do) */
+        if (n_ready >= thr || (n_ready > 0 && n_node + n_leaf <= 0)) {
+            idle_since = 0;
+            if (p.mode == M_SHADE) {
+                RT_STAT(ST_SHADE);
+                px_shade(p, a, f, L);
+            }
+            RT_LAP(TM_SHADE);
+            px_fetch(p, ch, a, f, lane);
+            RT_LAP(TM_FETCH);
+            if (p.mode == M_GEN) {
+                RT_STAT(ST_GEN);
+                px_gen<true>(p, a, L);
+            }
+            RT_LAP(TM_GEN);
+            /* MESH: the next mesh whose root box the ray enters; its traversal is posted */
+            bool submit = false;
+            uint32_t sub_root = 0;
+            while (p.mode == M_MESH) {
+                RT_STAT(ST_MESH);
+                if (p.next_mesh >= a.num_meshes) { p.mode = M_SHADE; break; }
+                const v4f m0 = L.meshes[2 * p.next_mesh], m1 = L.meshes[2 * p.next_mesh + 1];
+                p.next_mesh++;
+                /* a NaN direction (Box-Muller on a zero draw) fails every
+                 * triangle test: the mesh cannot be hit, no need to walk it */
+                if (p.d.x != p.d.x || p.d.y != p.d.y || p.d.z != p.d.z) continue;
+                /* the root is pushed unconditionally and tested when popped (src/objects.cu:494-501) */
+                const uint32_t root_ref = __float_as_uint(m1.z);
+                float rd;
+                const bool rh = box_test(m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, p.o, p.inv, rd);
+                if (!rh || rd > RT_INF_F || ((root_ref & RT_REF_CHAIN) && !(rd < RT_INF_F))) continue;
+                w_obj = (int)__float_as_uint(m1.w);
+                submit = true; sub_root = root_ref;
+                p.mode = M_WAIT;
+                RT_STAT(ST_MESH_START);
+            }
+            if (submit) {
+                v4f r0, r1, r2;
+                r0.x = p.o.x; r0.y = p.o.y; r0.z = p.o.z; r0.w = RT_INF_F;
+                r1.x = p.d.x; r1.y = p.d.y; r1.z = p.d.z; r1.w = __uint_as_float(sub_root);
+                r2.x = p.inv.x; r2.y = p.inv.y; r2.z = p.inv.z; r2.w = __uint_as_float(0u);
+                rq0[tid] = r0; rq1[tid] = r1; rq2[tid] = r2;
+            }
+            pool_push(ctl + C_NODE_TAIL, node_q, submit && !(sub_root & RT_REF_LEAF), (uint32_t)tid, ctl + C_ABORT);
+            pool_push(ctl + C_LEAF_TAIL, leaf_q, submit && (sub_root & RT_REF_LEAF), (uint32_t)tid, ctl + C_ABORT);
+            RT_LAP(TM_MESH);
+            n_node = __builtin_amdgcn_readfirstlane((int)(RT_LD(ctl + C_NODE_TAIL) - RT_LD(ctl + C_NODE_HEAD)));
+            n_leaf = __builtin_amdgcn_readfirstlane((int)(RT_LD(ctl + C_LEAF_TAIL) - RT_LD(ctl + C_LEAF_HEAD)));
+        }
+
+        if (n_leaf > 0 && (n_leaf >= n_node || n_leaf >= a.pool_leaf_batch)) {
+            /* ================= triangle-test executor: one batch ============================ */
+            idle_since = 0;
+            const int e_slot = pool_grab(ctl + C_LEAF_HEAD, leaf_q, true, lane, ctl + C_ABORT);
+            if (e_slot >= 0) {
+                const v4f r0 = rq0[e_slot], r1 = rq1[e_slot];
+                uint32_t e_meta = *REC_META(e_slot);
+                const V3 e_o = v3(r0.x, r0.y, r0.z), e_d = v3(r1.x, r1.y, r1.z);
+                float e_best = r0.w;
+                const uint32_t e_cur = __float_as_uint(r1.w);
+                /* leaf: strict <, first triangle wins ties (src/objects.cu:596) */
+                const int start = (int)(e_cur & RT_REF_START_MASK);
+                const int count = (int)((e_cur >> RT_REF_COUNT_SHIFT) & RT_REF_COUNT_MAX);
+                uint32_t e_prim1 = e_meta & RT_META_PRIM_MASK;
+                for (int k = 0; k < count; k++) {
+                    RT_STAT(ST_LEAF_TRI);
+                    float t, u, v;
+                    const bool h = tri_test(L.tris, start + k, e_o, e_d, t, u, v);
+                    if (h && t < e_best) { e_best = t; e_prim1 = (uint32_t)(start + k + 1); }
+                }
+                *REC_BEST(e_slot) = e_best;
+                const uint32_t e_sp = (e_meta >> RT_META_SP_SHIFT) & 31u;
+                const bool finished = e_sp == 0u;          /* nothing deferred: the traversal is over */
+                *REC_META(e_slot) = e_prim1 | (e_sp << RT_META_SP_SHIFT) | (finished ? 0u : RT_META_POP);
+                if (finished) RT_ST_REL(REC_CUR(e_slot), RT_POOL_DONE);
+                pool_push(ctl + C_NODE_TAIL, node_q, !finished, (uint32_t)e_slot, ctl + C_ABORT);
+            }
+            RT_LAP(TM_LEAF);
+        } else if (n_node > 0) {
+            /* ================= box-test executor =========================================== */
+            idle_since = 0;
+            int e_state = E_FREE, e_slot = 0, e_sp = 0;
+            V3 e_o = v3(0.f, 0.f, 0.f), e_inv = e_o;
+            float e_best = RT_INF_F;
+            uint32_t e_cur = 0, e_prim1 = 0;
+            for (;;) {
+                const int n_act = __popcll(__ballot(e_state == E_NODE || e_state == E_POP));
+                const int n_park = __popcll(__ballot(e_state >= E_PARK_LEAF));
+                if (n_act == 0 || RT_WAVE - n_act >= a.pool_fill || (n_park > 0 && n_act < a.pool_low)) {
+                    /* ---- hand on the rays that left the box-test phase ... */
+                    if (e_state == E_PARK_LEAF) {
+                        *REC_CUR(e_slot) = e_cur;
+                        *REC_META(e_slot) = e_prim1 | ((uint32_t)e_sp << RT_META_SP_SHIFT);
+                    }
+                    pool_push(ctl + C_LEAF_TAIL, leaf_q, e_state == E_PARK_LEAF, (uint32_t)e_slot, ctl + C_ABORT);
+                    if (e_state == E_PARK_DONE) RT_ST_REL(REC_CUR(e_slot), RT_POOL_DONE);
+                    if (e_state >= E_PARK_LEAF) e_state = E_FREE;
+                    /* ---- ... see whether my own pixels want me back ... */
+                    const bool mine = p.mode == M_WAIT && RT_LD(REC_CUR(tid)) == RT_POOL_DONE;
+                    const int n_mine = __popcll(__ballot(mine)) + n_ready;
+                    const bool preempt = n_mine >= thr;
+                    /* ---- ... and take on waiting rays */
+                    if (!preempt) {
+                        const int s = pool_grab(ctl + C_NODE_HEAD, node_q, e_state == E_FREE, lane, ctl + C_ABORT);
+                        if (s >= 0) {
+                            const v4f r0 = rq0[s], r2 = rq2[s];
+                            e_slot = s;
+                            e_o = v3(r0.x, r0.y, r0.z); e_best = r0.w;
+                            e_inv = v3(r2.x, r2.y, r2.z);
+                            const uint32_t meta = __float_as_uint(r2.w);
+                            e_cur = *REC_CUR(s);
+                            e_prim1 = meta & RT_META_PRIM_MASK;
+                            e_sp = (int)((meta >> RT_META_SP_SHIFT) & 31u);
+                            e_state = (meta & RT_META_POP) ? E_POP : E_NODE;
+                        }
+                    }
+                    const bool held = e_state == E_NODE || e_state == E_POP;
+                    if (preempt || __ballot(held) == 0ull) {
+                        /* leave: whatever is still in flight goes back on the queue */
+                        if (held) {
+                            *REC_CUR(e_slot) = e_cur;
+                            *REC_META(e_slot) = e_prim1 | ((uint32_t)e_sp << RT_META_SP_SHIFT) | (e_state == E_POP ? RT_META_POP : 0u);
+                        }
+                        pool_push(ctl + C_NODE_TAIL, node_q, held, (uint32_t)e_slot, ctl + C_ABORT);
+                        break;
+                    }
+                }
+                if (e_state == E_NODE || e_state == E_POP) {
+                    const bool popping = e_state == E_POP;
+                    if (popping && e_sp == 0) {
+                        e_state = E_PARK_DONE;          /* nothing deferred: the traversal is over */
+                    } else {
+                        RT_STAT(ST_NODE);
+                        /* a pop re-runs the two box tests of the node whose second child was deferred */
+                        uint32_t idx = e_cur & RT_REF_NODE_MASK;
+                        if (popping) { e_sp--; idx = (uint32_t)stack[e_sp * NT + e_slot]; }
+                        const v4f *n = L.nodes + 4 * (int)idx;
+                        const v4f q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+                        float ld, rdist;
+                        const bool lh = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, e_o, e_inv, ld);
+                        const bool rh2 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, e_o, e_inv, rdist);
+                        const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+                        const bool l_first = ld < rdist;
+                        /* Of two entered children the one pushed first (left when l_first) is
+                         * visited second: it is the deferred sibling (src/objects.cu:503-531). */
+                        const uint32_t deferred_ref = l_first ? lref : rref;
+                        const float deferred_d = l_first ? ld : rdist;
+                        if (popping) {
+                            /* an entry is taken iff !(dist > best) (:501); through a collapsed
+                             * chain iff dist < best (:517) */
+                            const bool take = (deferred_ref & RT_REF_CHAIN) ? (deferred_d < e_best) : !(deferred_d > e_best);
+                            if (take) {
+                                e_cur = deferred_ref;
+                                e_state = (deferred_ref & RT_REF_LEAF) ? E_PARK_LEAF : E_NODE;
+                            }
+                        } else {
+                            const bool l_push = lh && ld < e_best;
+                            const bool r_push = rh2 && rdist < e_best;
+                            const bool both = l_push && r_push;
+                            const bool entered = l_push || r_push;
+                            stack[e_sp * NT + e_slot] = (uint16_t)idx;
+                            e_sp += both ? 1 : 0;
+                            const uint32_t next = both ? (l_first ? rref : lref) : (l_push ? lref : rref);
+                            if (entered) {
+                                e_cur = next;
+                                if (next & RT_REF_LEAF) e_state = E_PARK_LEAF;
+                            } else {
+                                e_state = E_POP;
+                            }
+                        }
+                    }
+                }
+            }
+            RT_LAP(TM_DESCEND);
+        } else {
+            /* ---- nothing to execute */
+            if (!retired && __ballot(p.mode != M_DONE) == 0ull) {
+                retired = true;
+                if (lane == 0) __hip_atomic_fetch_sub(ctl + C_LIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            const uint32_t live = (uint32_t)__builtin_amdgcn_readfirstlane((int)RT_LD(ctl + C_LIVE));
+            const uint32_t aborted = (uint32_t)__builtin_amdgcn_readfirstlane((int)RT_LD(ctl + C_ABORT));
+            if ((retired && live == 0u) || aborted) break;
+            if (n_ready == 0) {
+                /* watchdog: no wave of a healthy workgroup idles this long (100 MHz ticks) */
+                const unsigned long long now = wall_clock64();
+                if (idle_since == 0) idle_since = now;
+                if (now - idle_since > 3000000000ull) { RT_ST(ctl + C_ABORT, 1u); }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            RT_LAP(TM_POP);
+        }
+    }
+    if (lane == 0 && RT_LD(ctl + C_ABORT)) atomicAdd(a.tile_counter + 1, 1u);
+    RT_STATS_FLUSH();
+#undef REC_BEST
+#undef REC_CUR
+#undef REC_META
 }
 
 /* float -> RGBA8 of src/main.cu:343-371 */
@@ -735,6 +707,31 @@ static void rt_launch_one(const rt_kernel_args *args, int blocks, size_t lds_byt
 {
     (void)hipFuncSetAttribute((const void *)rt_render_kernel<NT, HAS_MESH, SCENE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL((rt_render_kernel<NT, HAS_MESH, SCENE_LDS>), dim3(blocks), dim3(NT), lds_bytes, stream, *args);
+}
+
+template <int NT, bool SCENE_LDS>
+static void rt_launch_pool(const rt_kernel_args *args, int blocks, size_t lds_bytes, hipStream_t stream)
+{
+    (void)hipFuncSetAttribute((const void *)rt_render_pool_kernel<NT, SCENE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((rt_render_pool_kernel<NT, SCENE_LDS>), dim3(blocks), dim3(NT), lds_bytes, stream, *args);
+}
+
+/* mesh scenes, pooled traversal */
+extern "C" hipError_t rt_launch_render_pool(const rt_kernel_args *args, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream)
+{
+    if (!scene_in_lds) {
+        if (threads != 1024) return hipErrorInvalidValue;
+        rt_launch_pool<1024, false>(args, blocks, lds_bytes, stream);
+        return hipGetLastError();
+    }
+    switch (threads) {
+        case 256: rt_launch_pool<256, true>(args, blocks, lds_bytes, stream); break;
+        case 512: rt_launch_pool<512, true>(args, blocks, lds_bytes, stream); break;
+        case 768: rt_launch_pool<768, true>(args, blocks, lds_bytes, stream); break;
+        case 1024: rt_launch_pool<1024, true>(args, blocks, lds_bytes, stream); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream)

@@ -1,0 +1,469 @@
+/*
+ * rt_pixel.h — device code shared by the render kernels of rt_kernel.hip: vector helpers, the
+ * primitive tests, and the three per-pixel sections of the lane state machine (SHADE, FETCH, GEN).
+ *
+ * The arithmetic (types, order, the double-precision fragments) is the reference's; file:line
+ * citations are on each piece.  -ffp-contract=off is assumed (see rt_kernel.hip).
+ */
+#ifndef RT_PIXEL_H
+#define RT_PIXEL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device_scene.h"
+#include "rt_math.h"
+#include "rt_rng.h"
+
+#define RT_WAVE 64
+
+/* 16-byte vector for LDS / global accesses: a single ds_read_b128 / global_load_dwordx4 each
+ * (a struct of four floats gets split into narrower loads by the optimiser) */
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct V3 { float x, y, z; };
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+/* src/utils.cu:130-136: (x*x' + y*y') + z*z' */
+__device__ __forceinline__ float dot(V3 a, V3 b) { float nx = a.x * b.x, ny = a.y * b.y, nz = a.z * b.z; return nx + ny + nz; }
+/* src/utils.cu:146-153 */
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+/* src/utils.cu:118-128: one reciprocal of the magnitude, three multiplies */
+__device__ __forceinline__ V3 normalised(V3 a)
+{
+    float m = a.x * a.x + a.y * a.y + a.z * a.z;
+    float inv = 1.0f / sqrtf(m);
+    return v3(a.x * inv, a.y * inv, a.z * inv);
+}
+__device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
+
+/* src/utils.cu:234-239 — Box-Muller cosine branch, theta drawn first.  rt_rng.h produces the
+ * reference's (float)(r / 4294967295.0) and the binary64 products derived from it without the
+ * binary64 divide, bit for bit (tests/test_rng_exhaustive.py covers all 2^32 inputs). */
+__device__ __forceinline__ float normal_num(uint32_t &state)
+{
+    float theta = rt_theta(rt_pcg_next(&state));
+    float rho = sqrtf(-2.0f * rt_logf(rt_u01(rt_pcg_next(&state))));
+    return rho * rt_cosf(theta);
+}
+
+/* the scene sections (LDS, or global memory for scenes larger than a CU's LDS) */
+struct Lds {
+    const v4f *nodes;
+    const v4f *tris;
+    const v4f *objs;
+    const v4f *meshes;
+    const v4f *objtab;   /* the object list (rt_object, 3 x 16 B each), read with wave-uniform addresses */
+};
+
+/* BoundingBox::ray_hits src/objects.cu:404-434.  fminf/fmaxf drop a NaN operand like CUDA's
+ * min/max; the result only ever feeds comparisons, so the sign of a zero is irrelevant. */
+__device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
+                                         V3 o, V3 inv, float &tmin_out)
+{
+    float tmin = 0.0f, tmax = RT_INF_F;
+    float t1 = (bx0 - o.x) * inv.x, t2 = (bx1 - o.x) * inv.x;
+    tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+    t1 = (by0 - o.y) * inv.y; t2 = (by1 - o.y) * inv.y;
+    tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+    t1 = (bz0 - o.z) * inv.z; t2 = (bz1 - o.z) * inv.z;
+    tmin = fmaxf(tmin, fminf(t1, t2)); tmax = fminf(tmax, fmaxf(t1, t2));
+    tmin_out = tmin;
+    return tmin < tmax && tmax > 0.0f;
+}
+
+/* Triangle::hit src/objects.cu:135-163 (Moller-Trumbore, two-sided, no early out) */
+__device__ __forceinline__ bool tri_test(const v4f *tris, int idx, V3 o, V3 d, float &t_out, float &u_out, float &v_out)
+{
+    v4f q0 = tris[3 * idx], q1 = tris[3 * idx + 1], q2 = tris[3 * idx + 2];
+    V3 p0 = v3(q0.x, q0.y, q0.z), s1 = v3(q0.w, q1.x, q1.y), s2 = v3(q1.z, q1.w, q2.x);
+    V3 p_vec = cross(d, s2);
+    float det = dot(s1, p_vec);
+    float inv_det = 1.0f / det;
+    V3 t_vec = o - p0;
+    float u = dot(t_vec, p_vec) * inv_det;
+    V3 q_vec = cross(t_vec, s1);
+    float v = dot(d, q_vec) * inv_det;
+    float w = 1.0f - u - v;
+    float dist = dot(s2, q_vec) * inv_det;
+    t_out = dist; u_out = u; v_out = v;
+    return dist > RT_EPS_F && u >= 0.0f && v >= 0.0f && w >= 0.0f;
+}
+
+/* Quad::hit src/objects.cu:223-236 — t1 if it hits, whatever t2's distance; else t2 */
+__device__ __forceinline__ bool quad_test(const v4f *tris, int first, V3 o, V3 d, float &t_out, int &prim_out)
+{
+    float t1, t2, u, v;
+    bool h1 = tri_test(tris, first, o, d, t1, u, v);
+    bool h2 = tri_test(tris, first + 1, o, d, t2, u, v);
+    t_out = h1 ? t1 : t2;
+    prim_out = h1 ? first : first + 1;
+    return h1 || h2;
+}
+
+/* lane states of the render loop */
+enum { M_FETCH = 0, M_GEN = 1, M_MESH = 2, M_WAIT = 3, M_SHADE = 4, M_DONE = 5 };
+
+/* per-lane pixel state (registers) */
+struct Px {
+    int mode;
+    uint32_t rng;
+    V3 colour, fin, thr, o, d, inv, primary;
+    int sample, bounce, px, py;
+    float cur_n;                 /* Ray::current_refractive_index src/ray.cu:56,144 */
+    float best_t;
+    int best_obj, best_prim, next_mesh;
+#ifdef RT_COSTMAP
+    /* development build (tools/costmap.py): the frame holds, per pixel, (own traversal steps,
+     * start tick, end tick) of the 100 MHz wall clock instead of the colour */
+    unsigned c_steps, c_t0, c_wsteps;
+#endif
+};
+#ifdef RT_COSTMAP
+#define RT_COST(x) do { x; } while (0)
+#else
+#define RT_COST(x) do { } while (0)
+#endif
+
+/* wave-uniform frame constants */
+struct Frame {
+    V3 cam_pos, tl, du, dv, sky;
+    int W, H, spp, limit, tiles_per_band;
+};
+
+/* wave-uniform pixel chunk: linear pixel ids [next, end) of one 8x8 tile */
+struct Chunk {
+    uint32_t next, end;
+    bool exhausted;
+};
+
+__device__ __forceinline__ void px_init(Px &p)
+{
+    const V3 z = v3(0.f, 0.f, 0.f);
+    p.mode = M_FETCH; p.rng = 0;
+    p.colour = z; p.fin = z; p.thr = z; p.o = z; p.d = z; p.inv = z; p.primary = z;
+    p.sample = 0; p.bounce = 0; p.px = 0; p.py = 0;
+    p.cur_n = 1.0f; p.best_t = RT_INF_F;
+    p.best_obj = -1; p.best_prim = -1; p.next_mesh = 0;
+    RT_COST(p.c_steps = 0; p.c_t0 = 0; p.c_wsteps = 0);
+}
+
+__device__ __forceinline__ void frame_init(Frame &f, const rt_kernel_args &a)
+{
+    f.cam_pos = v3(a.cam[0], a.cam[1], a.cam[2]);
+    f.tl = v3(a.cam[3], a.cam[4], a.cam[5]);
+    f.du = v3(a.cam[6], a.cam[7], a.cam[8]);
+    f.dv = v3(a.cam[9], a.cam[10], a.cam[11]);
+    f.sky = v3(a.sky[0], a.sky[1], a.sky[2]);
+    f.W = a.width; f.H = a.height;
+    f.spp = a.rays_per_pixel; f.limit = a.reflection_limit;
+    f.tiles_per_band = a.tiles_x * (a.band_rows >> 3);
+}
+
+/* ================= SHADE: the closest hit of this bounce is known ======================== */
+__device__ __forceinline__ void px_shade(Px &p, const rt_kernel_args &a, const Frame &f, const Lds &L)
+{
+    V3 &o = p.o, &d = p.d;
+    bool end_sample;
+    if (p.best_obj < 0) {
+        /* src/raytracer.cu:76-80 */
+        p.fin = p.fin + f.sky * p.thr;
+        end_sample = true;
+    } else {
+        const int best_obj = p.best_obj, best_prim = p.best_prim;
+        const v4f ma = L.objs[RT_OBJLDS_F4 * best_obj], mb = L.objs[RT_OBJLDS_F4 * best_obj + 1];
+        const uint32_t packed = __float_as_uint(mb.w);
+        const int mtype = (int)(packed & 3u);
+        /* hit point and normal: Ray::get_pos src/ray.cu:63-65; Sphere :66; Triangle :158 */
+        V3 P = d * p.best_t + o;
+        V3 N;
+        float tex_u = 0.f, tex_v = 0.f;
+        if (packed & 32u) {
+            const v4f sc = L.objs[RT_OBJLDS_F4 * best_obj + 2];
+            N = normalised(P - v3(sc.x, sc.y, sc.z));
+            if (packed & 16u) {
+                /* Sphere::assign_texture_coords src/objects.cu:82-97 (latitude / longitude) */
+                const float PI = 3.141592653589793f;
+                const float theta = rt_asinf((P.y - sc.y) / sc.w);
+                const float phi = rt_acosf((P.x - sc.x) / sc.w);
+                tex_u = (theta + PI / 2) / PI;
+                const float v_ratio = (1 - phi / PI) / 2;
+                const int behind = P.z > sc.z ? 1 : 0;
+                const int mult = 1 - 2 * behind;
+                tex_v = (float)(1 * behind) + (float)mult * v_ratio;
+            }
+        } else {
+            const v4f q2 = L.tris[3 * best_prim + 2];
+            V3 n = v3(q2.y, q2.z, q2.w);
+            N = (dot(n, d) > 0.0f) ? neg(n) : n;
+            if (packed & 16u) {
+                /* Triangle::assign_texture_coords src/objects.cu:160,196-199, called as (w,u,v) */
+                float t, u, v;
+                tri_test(L.tris, best_prim, o, d, t, u, v);
+                float w = 1.0f - u - v;
+                const float *uv = a.tri_uv + 6 * best_prim;
+                tex_u = uv[0] * w + uv[2] * u + uv[4] * v;
+                tex_v = uv[1] * w + uv[3] * u + uv[5] * v;
+            }
+        }
+        /* update_ray src/raytracer.cu:49-64: REFRACTIVE goes through Ray::refract
+         * (src/ray.cu:77-128, Snell + Schlick + total internal reflection), which falls
+         * back to reflect(); everything else reflects */
+        bool do_reflect = true;
+        V3 refr_dir = v3(0.f, 0.f, 0.f);
+        if (mtype == RT_DEV_MAT_REFRACTIVE) {
+            const float mat_n = L.objs[RT_OBJLDS_F4 * best_obj + 3].x;
+            float n1, n2;
+            V3 rn;
+            if (dot(N, d) > 0.0f) { n1 = mat_n; n2 = p.cur_n; rn = N; }        /* leaving the object */
+            else                  { n1 = p.cur_n; n2 = mat_n; rn = neg(N); }   /* entering */
+            p.cur_n = n2;
+            /* min(float, double) is CUDA's double overload; acos / asin of doubles */
+            const float theta1 = (float)rt_acos(fmin((double)dot(d, rn), 1.0));
+            const float theta2 = (float)rt_asin(fmin((double)(n1 * rt_sinf(theta1) / n2), 1.0));
+            const float critical_angle = rt_asinf(n2 / n1);
+            /* get_reflection_coeff :188-196: pow(float, int) is the double pow */
+            const float sqrt_r0 = (n1 - n2) / (n1 + n2);
+            const float r0 = sqrt_r0 * sqrt_r0;
+            const float cos_theta = rt_cosf(theta1);
+            const float reflection_coeff = (float)((double)r0 + (double)(1.0f - r0) * rt_pow5((double)(1.0f - cos_theta)));
+            do_reflect = theta1 > critical_angle;
+            if (!do_reflect) do_reflect = reflection_coeff > rt_u01(rt_pcg_next(&p.rng));   /* `||` short-circuits */
+            if (!do_reflect) {
+                V3 perp = v3(0.f, 0.f, 0.f);
+                if (theta1 != 0.0f) perp = (d - rn * rt_cosf(theta1)) / rt_sinf(theta1);
+                refr_dir = normalised(rn * rt_cosf(theta2) + perp * rt_sinf(theta2));
+            }
+        }
+        if (do_reflect) {
+            /* Ray::reflect src/ray.cu:67-75 with diffuse_reflect :157-170,
+             * true_lambertian_reflect :172-178, perfect_reflect :180-186, lerp :32-34 */
+            float gx = normal_num(p.rng);
+            float gy = normal_num(p.rng);
+            float gz = normal_num(p.rng);
+            V3 rv = v3(gx, gy, gz);
+            if (dot(rv, N) < 0.0f) rv = neg(rv);
+            rv = normalised(rv);
+            V3 diffuse_dir = normalised(N + rv);
+            float dn = dot(d, N);
+            V3 specular_dir = normalised(d - (N * 2.0f) * dn);
+            d = normalised(diffuse_dir + (specular_dir - diffuse_dir) * ma.w);
+        } else {
+            d = refr_dir;
+        }
+        o = P;
+
+        /* src/raytracer.cu:86-90 */
+        if (mtype == RT_DEV_MAT_EMISSIVE) {
+            p.fin = p.fin + v3(mb.x, mb.y, mb.z) * p.thr;
+        } else {
+            V3 tc;
+            const int tex = (int)((packed >> 2) & 3u);
+            if (tex == 0) {
+                tc = v3(ma.x, ma.y, ma.z);
+            } else if (tex == 1) {
+                tc = v3(tex_u, tex_v, 0.f);                              /* gradient src/material.cu:80-82 */
+            } else if (tex == 3) {
+                /* image src/material.cu:119-124: nearest texel; an out-of-range index is clamped */
+                const int iw = (int)__float_as_uint(ma.x), ih = (int)__float_as_uint(ma.y);
+                const int uc = (int)((float)(iw - 1) * tex_u), vc = (int)((float)(ih - 1) * tex_v);
+                int idx = vc * iw + uc;
+                idx = idx < 0 ? 0 : (idx > iw * ih - 1 ? iw * ih - 1 : idx);
+                const float *tx = a.tex_data + (size_t)__float_as_uint(ma.z) + 3 * (size_t)idx;
+                tc = v3(tx[0], tx[1], tx[2]);
+            } else {
+                const int nsq = (int)(packed >> 8);                      /* checkerboard :90-99 */
+                int uc = (int)(tex_u * (float)nsq), vc = (int)(tex_v * (float)nsq);
+                tc = ((uc + vc) % 2 == 0) ? v3(ma.x, ma.y, ma.z) : v3(mb.x, mb.y, mb.z);
+            }
+            p.thr = p.thr * tc;
+        }
+        p.bounce++;
+        end_sample = p.bounce >= f.limit;
+    }
+    p.mode = M_GEN;
+    if (end_sample) {
+        /* src/raytracer.cu:102-105: the next sample restarts from a copy of the primary ray */
+        p.colour = p.colour + p.fin;
+        p.sample++;
+        p.fin = v3(0.f, 0.f, 0.f); p.thr = v3(1.f, 1.f, 1.f);
+        o = f.cam_pos; d = p.primary; p.bounce = 0; p.cur_n = 1.0f;
+        if (p.sample >= f.spp) {
+            /* src/raytracer.cu:107-112 and :133-135 */
+            const int array_index = (p.py * f.W + p.px) * 3;
+            V3 c = p.colour / (float)f.spp;
+            V3 previous = v3(0.f, 0.f, 0.f);
+            if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
+            V3 previous_sum = previous * (float)a.frame_num;
+            V3 res = (c + previous_sum) / (float)(a.frame_num + 1);
+            int out_row = p.py;
+            if (a.compact) {
+                const int band = p.py / a.band_rows;
+                out_row = ((band - a.band_first) / a.band_stride) * a.band_rows + (p.py - band * a.band_rows);
+            }
+            float *dst = a.out + ((size_t)out_row * (size_t)f.W + (size_t)p.px) * 3;
+#ifdef RT_COSTMAP
+            res = v3(__uint_as_float(RT_COSTMAP == 2 ? p.c_wsteps : p.c_steps), __uint_as_float(p.c_t0), __uint_as_float((unsigned)wall_clock64()));
+#endif
+            dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+            p.mode = M_FETCH;
+        }
+    }
+}
+
+/* ================= FETCH: lanes without a pixel take the next ones =========================
+ * Linear pixel ids are tile-major (64 per 8x8 tile), tiles come from a global counter; a wave
+ * asks for one tile at a time and hands its ids out to whichever lanes are free.  Must be called
+ * by the whole wave. */
+__device__ __forceinline__ void px_fetch(Px &p, Chunk &ch, const rt_kernel_args &a, const Frame &f, int lane)
+{
+    const bool want = p.mode == M_FETCH;
+    const unsigned long long mask = __ballot(want);
+    if (!mask) return;
+    const int need = __popcll(mask);
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+    int taken = 0;
+    int my_id = -1;
+    for (;;) {
+        const int avail = (int)(ch.end - ch.next);
+        const int take = avail < need - taken ? avail : need - taken;
+        if (want && rank >= taken && rank < taken + take) my_id = (int)ch.next + (rank - taken);
+        ch.next += (uint32_t)take;
+        taken += take;
+        if (taken == need || ch.exhausted) break;
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(a.tile_counter, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t >= (uint32_t)a.num_tiles) { ch.exhausted = true; break; }
+        /* ticket -> tile through a permutation.  A pixel's samples are sequential, so the frame
+         * cannot finish before its most expensive tile does; the host therefore lists the tiles
+         * whose centre ray enters a mesh box first (longest-job-first), each class scattered by a
+         * stride coprime to the tile count so that neighbouring (equally expensive) tiles do not
+         * land on the waves of one CU.  Any order gives the same image. */
+        t = a.tile_order ? a.tile_order[t]
+                         : (uint32_t)(((unsigned long long)t * (unsigned long long)a.tile_stride) % (unsigned long long)a.num_tiles);
+        ch.next = t * 64u;
+        ch.end = t * 64u + 64u;
+    }
+    if (!want) return;
+    if (my_id < 0) { p.mode = M_DONE; return; }
+    const int tile = my_id >> 6, within = my_id & 63;
+    const int band_local = tile / f.tiles_per_band;
+    const int in_band = tile - band_local * f.tiles_per_band;
+    const int band = a.band_first + band_local * a.band_stride;
+    const int ty = in_band / a.tiles_x, tx = in_band - ty * a.tiles_x;
+    p.px = tx * 8 + (within & 7);
+    p.py = band * a.band_rows + ty * 8 + (within >> 3);
+    if (p.px < f.W && p.py < f.H) {
+        /* src/raytracer.cu:123-127; Ray::set_direction_origin src/ray.cu:147-155,
+         * cam_pixel_to_world src/camera.cu:24-29 */
+        const int array_index = (p.py * f.W + p.px) * 3;
+        p.rng = (uint32_t)array_index * 3145739u + a.seed_time;
+        RT_COST(p.c_steps = 0; p.c_wsteps = 0; p.c_t0 = (unsigned)wall_clock64());
+        V3 plane_point = f.du * (float)p.px + f.dv * (float)p.py;
+        p.primary = normalised((f.tl + plane_point) - f.cam_pos);
+        p.colour = v3(0.f, 0.f, 0.f);
+        p.fin = v3(0.f, 0.f, 0.f); p.thr = v3(1.f, 1.f, 1.f);
+        p.o = f.cam_pos; p.d = p.primary;
+        p.bounce = 0; p.cur_n = 1.0f;
+        /* a zero bounce limit traces nothing: every sample is (0,0,0) */
+        p.sample = f.limit > 0 ? 0 : f.spp;
+        if (p.sample >= f.spp) {
+            const float q = 0.0f / (float)f.spp;               /* NaN for spp == 0, like the reference */
+            V3 previous = v3(0.f, 0.f, 0.f);
+            if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
+            V3 res = (v3(q, q, q) + previous * (float)a.frame_num) / (float)(a.frame_num + 1);
+            int out_row = p.py;
+            if (a.compact) out_row = band_local * a.band_rows + (p.py - band * a.band_rows);
+            float *dst = a.out + ((size_t)out_row * (size_t)f.W + (size_t)p.px) * 3;
+            dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+            /* stays in M_FETCH: takes another pixel next time round */
+        } else {
+            p.mode = M_GEN;
+        }
+    }
+    /* a pixel outside the image (ragged edge tile): stay in M_FETCH */
+}
+
+/* ================= GEN: jitter the direction, test the simple objects ====================== */
+template <bool HAS_MESH>
+__device__ __forceinline__ void px_gen(Px &p, const rt_kernel_args &a, const Lds &L)
+{
+    V3 &o = p.o, &d = p.d;
+    /* Ray::apply_antialias src/ray.cu:130-142 */
+    if (a.antialias) {
+        V3 off;
+        off.x = rt_jitter(rt_pcg_next(&p.rng));
+        off.y = rt_jitter(rt_pcg_next(&p.rng));
+        off.z = rt_jitter(rt_pcg_next(&p.rng));
+        d = normalised(d + off);
+    }
+    if (HAS_MESH) p.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   /* src/ray.cu:198-202 */
+
+    /* get_ray_collision src/raytracer.cu:24-46 over the non-mesh objects, in list order
+     * (`<=`: the later object wins ties, :36; the precision_error term is a no-op for
+     * accepted hits).  Meshes are merged afterwards with the same
+     * rule made explicit: smaller distance, or equal distance and larger list index. */
+    float best_t = RT_INF_F;
+    int best_obj = -1, best_prim = -1;
+    for (int i = 0; i < a.num_objects; i++) {
+        /* rt_object from LDS: every lane reads the same address (broadcast) */
+        const v4f ob0 = L.objtab[3 * i], ob1 = L.objtab[3 * i + 1], ob2 = L.objtab[3 * i + 2];
+        rt_object ob;
+        ob.type = (int32_t)__float_as_uint(ob0.x); ob.prim_start = (int32_t)__float_as_uint(ob0.y);
+        ob.need_uv = (int32_t)__float_as_uint(ob0.z); ob.root_ref = __float_as_uint(ob0.w);
+        ob.v[0] = ob1.x; ob.v[1] = ob1.y; ob.v[2] = ob1.z; ob.v[3] = ob1.w;
+        ob.v[4] = ob2.x; ob.v[5] = ob2.y; ob.v[6] = ob2.z; ob.v[7] = ob2.w;
+        bool hit = false;
+        float t = RT_INF_F;
+        int prim = -1;
+        switch (ob.type) {
+            case RT_OBJ_SPHERE: {   /* Sphere::hit src/objects.cu:40-79: near root, > 1e-6 */
+                V3 cq = v3(ob.v[0], ob.v[1], ob.v[2]) - o;
+                float qa = dot(d, d);
+                float qb = dot(d, cq) * (-2.0f);
+                float qc = dot(cq, cq) - ob.v[3] * ob.v[3];
+                float disc = qb * qb - 4.0f * qa * qc;
+                if (disc >= 0.0f) {
+                    float dist = (-qb - sqrtf(disc)) / (2.0f * qa);
+                    if (dist > RT_EPS_F) { hit = true; t = dist; }
+                }
+                break;
+            }
+            case RT_OBJ_TRIANGLE: {
+                float u, v;
+                hit = tri_test(L.tris, ob.prim_start, o, d, t, u, v);
+                prim = ob.prim_start;
+                break;
+            }
+            case RT_OBJ_ONE_WAY_QUAD:   /* src/objects.cu:273-280 */
+                if (dot(d, v3(ob.v[0], ob.v[1], ob.v[2])) < 0.0f) break;
+                /* fall through */
+            case RT_OBJ_QUAD:
+                hit = quad_test(L.tris, ob.prim_start, o, d, t, prim);
+                break;
+            case RT_OBJ_CUBOID: {       /* src/objects.cu:305-322: strict <, first face wins ties */
+                float cb = RT_INF_F;
+                for (int fc = 0; fc < 6; fc++) {
+                    float ft; int fp;
+                    bool fh = quad_test(L.tris, ob.prim_start + 2 * fc, o, d, ft, fp);
+                    if (fh && ft < cb) { cb = ft; prim = fp; hit = true; }
+                }
+                t = cb;
+                break;
+            }
+            default: break;             /* RT_OBJ_MESH: traversed separately */
+        }
+        if (hit && t <= best_t) { best_t = t; best_obj = i; best_prim = prim; }
+    }
+    p.best_t = best_t; p.best_obj = best_obj; p.best_prim = best_prim;
+    p.next_mesh = 0;
+    p.mode = (HAS_MESH && a.num_meshes > 0) ? M_MESH : M_SHADE;
+}
+
+#endif
