@@ -52,9 +52,11 @@ enum { TM_CTL = 0, TM_SHADE = 1, TM_FETCH = 2, TM_GEN = 3, TM_MESH = 4, TM_DESCE
 /* inside the divergent `if (w_active)` block: leave it, lap with every lane, enter it again (the
  * timers are per-lane registers; only laps that all lanes execute measure the wave) */
 #define RT_LAP_SPLIT(slot) } RT_LAP(slot); if (w_active) {
+#define RT_LAP_SPLIT_LEAF(slot) } } RT_LAP(slot); if (w_active) { if (cur & RT_REF_LEAF) {
 #else
 #define RT_LAP(slot) do { } while (0)
 #define RT_LAP_SPLIT(slot)
+#define RT_LAP_SPLIT_LEAF(slot)
 #endif
 enum { ST_ITER = 0, ST_SHADE = 1, ST_SHADE_HIT = 2, ST_FETCH = 3, ST_GEN = 4, ST_MESH = 5, ST_MESH_START = 6, ST_WORK_ITER = 7, ST_NODE = 8, ST_LEAF_TRI = 9, ST_POP = 10, ST_DONE_MESH = 11, ST_N = 12 };
 
@@ -176,15 +178,15 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
 #if defined(RT_COSTMAP) && RT_COSTMAP == 2
                 p.c_wsteps += 1;      /* wave-level macro steps this lane lived through */
 #endif
-                bool at_leaf = false, need_pop = false;
                 RT_LAP(TM_CTL);
                 if (w_active) {
                     RT_STAT(ST_WORK_ITER);
                     /* one macro step: descend to a leaf (or run out of children), test the
-                     * leaf's triangles, pop the next deferred sibling. */
-                    at_leaf = (cur & RT_REF_LEAF) != 0u;
-                    need_pop = at_leaf;
-                    if (!at_leaf) {
+                     * leaf's triangles, pop the next deferred sibling.  The lane's whole
+                     * traversal state is `cur` (+ the stack): an internal node to descend from,
+                     * or a leaf whose triangles are tested and after which the stack is popped;
+                     * "no child entered" is the empty leaf. */
+                    if (!(cur & RT_REF_LEAF)) {
                         /* The body is branch-free: the deferred sibling is ALWAYS written to the
                          * slot above the top of the stack (one 8-byte LDS store) and the stack
                          * pointer moves only when both children are entered, so the only
@@ -218,15 +220,13 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                             stack[sp * NT + tid] = make_uint2(__float_as_uint(deferred_d), deferred_ref);
                             sp += both ? 1 : 0;
                             const uint32_t next = both ? (l_first ? rref : lref) : (l_push ? lref : rref);
-                            cur = entered ? next : cur;
-                            at_leaf = entered && (next & RT_REF_LEAF) != 0u;
-                            need_pop = !entered || at_leaf;
-                            if (need_pop) break;
+                            cur = entered ? next : RT_REF_EMPTY_LEAF;
+                            if (cur & RT_REF_LEAF) break;
                             if (__popcll(__ballot(1)) < n_keep) break;      /* wave-uniform */
                         }
                     }
                     RT_LAP_SPLIT(TM_DESCEND)
-                    if (at_leaf) {
+                    if (cur & RT_REF_LEAF) {
                         /* leaf: strict <, first triangle wins ties (:596) */
                         const int start = (int)(cur & RT_REF_START_MASK);
                         const int count = (int)((cur >> RT_REF_COUNT_SHIFT) & RT_REF_COUNT_MAX);
@@ -237,28 +237,28 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                             bool h = tri_test(L.tris, start + k, o, d, t, u, v);
                             if (h && t < w_best) { w_best = t; w_prim = start + k; }
                         }
-                    }
-                    /* pop: an entry is taken iff !(dist > best) (:501); through a collapsed chain
-                     * iff dist < best (:517) */
-                    RT_LAP_SPLIT(TM_LEAF)
-                    bool found = !need_pop;                 /* still descending: nothing to pop */
-                    while (need_pop && sp > 0) {
-                        RT_STAT(ST_POP);
-                        sp--;
-                        const uint2 e = stack[sp * NT + tid];
-                        const float dd = __uint_as_float(e.x);
-                        const uint32_t rr = e.y;
-                        const bool take = (rr & RT_REF_CHAIN) ? (dd < w_best) : !(dd > w_best);
-                        if (take) { cur = rr; found = true; break; }
-                    }
-                    if (!found) {
-                        RT_STAT(ST_DONE_MESH);
-                        /* this mesh is done: merge (smaller distance, or equal and later in the list) */
-                        if (w_prim >= 0 && (w_best < p.best_t || (w_best == p.best_t && w_obj > p.best_obj))) {
-                            p.best_t = w_best; p.best_obj = w_obj; p.best_prim = w_prim;
+                        RT_LAP_SPLIT_LEAF(TM_LEAF)
+                        /* pop: an entry is taken iff !(dist > best) (:501); through a collapsed chain
+                         * iff dist < best (:517) */
+                        bool found = false;
+                        while (sp > 0) {
+                            RT_STAT(ST_POP);
+                            sp--;
+                            const uint2 e = stack[sp * NT + tid];
+                            const float dd = __uint_as_float(e.x);
+                            const uint32_t rr = e.y;
+                            const bool take = (rr & RT_REF_CHAIN) ? (dd < w_best) : !(dd > w_best);
+                            if (take) { cur = rr; found = true; break; }
                         }
-                        w_active = false;
-                        p.mode = p.next_mesh >= a.num_meshes ? M_SHADE : M_MESH;
+                        if (!found) {
+                            RT_STAT(ST_DONE_MESH);
+                            /* this mesh is done: merge (smaller distance, or equal and later in the list) */
+                            if (w_prim >= 0 && (w_best < p.best_t || (w_best == p.best_t && w_obj > p.best_obj))) {
+                                p.best_t = w_best; p.best_obj = w_obj; p.best_prim = w_prim;
+                            }
+                            w_active = false;
+                            p.mode = p.next_mesh >= a.num_meshes ? M_SHADE : M_MESH;
+                        }
                     }
                 }
                 RT_LAP(TM_POP);
