@@ -51,8 +51,8 @@ enum { TM_CTL = 0, TM_SHADE = 1, TM_FETCH = 2, TM_GEN = 3, TM_MESH = 4, TM_DESCE
 #define RT_LAP(slot) do { unsigned long long now_ = __builtin_readcyclecounter(); st_time[slot] += now_ - st_last; st_last = now_; } while (0)
 /* inside the divergent `if (w_active)` block: leave it, lap with every lane, enter it again (the
  * timers are per-lane registers; only laps that all lanes execute measure the wave) */
-#define RT_LAP_SPLIT(slot) } RT_LAP(slot); if (w_active) {
-#define RT_LAP_SPLIT_LEAF(slot) } } RT_LAP(slot); if (w_active) { if (cur & RT_REF_LEAF) {
+#define RT_LAP_SPLIT(slot) } RT_LAP(slot); if (p.mode == M_WAIT) {
+#define RT_LAP_SPLIT_LEAF(slot) } } RT_LAP(slot); if (p.mode == M_WAIT) { if (cur & RT_REF_LEAF) {
 #else
 #define RT_LAP(slot) do { } while (0)
 #define RT_LAP_SPLIT(slot)
@@ -112,8 +112,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
     frame_init(f, a);
     Px p;
     px_init(p);
-    /* ---- per-lane traversal state (registers + LDS stack) ---- */
-    bool w_active = false;
+    /* ---- per-lane traversal state (registers + LDS stack); a lane is traversing iff M_WAIT ---- */
     uint32_t cur = 0;
     int sp = 0, w_prim = -1, w_obj = -1;
     float w_best = RT_INF_F;
@@ -159,7 +158,6 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                 const bool rh = box_test(m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, p.o, p.inv, rd);
                 if (!rh || rd > RT_INF_F || ((root_ref & RT_REF_CHAIN) && !(rd < RT_INF_F))) continue;
                 cur = root_ref; sp = 0; w_best = RT_INF_F; w_prim = -1; w_obj = (int)__float_as_uint(m1.w);
-                w_active = true;
                 p.mode = M_WAIT;
                 RT_STAT(ST_MESH_START);
             }
@@ -171,7 +169,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
              * every comparison are the reference's. */
             const V3 o = p.o, d = p.d, inv = p.inv;
             for (;;) {
-                const int n_active = __popcll(__ballot(w_active));
+                const int n_active = __popcll(__ballot(p.mode == M_WAIT));
                 if (n_active == 0) break;
                 const int n_ready = __popcll(__ballot(p.mode != M_WAIT && p.mode != M_DONE));
                 if (n_ready > 0 && (n_active < a.work_threshold || n_ready >= a.ready_break)) break;
@@ -179,7 +177,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                 p.c_wsteps += 1;      /* wave-level macro steps this lane lived through */
 #endif
                 RT_LAP(TM_CTL);
-                if (w_active) {
+                if (p.mode == M_WAIT) {
                     RT_STAT(ST_WORK_ITER);
                     /* one macro step: descend to a leaf (or run out of children), test the
                      * leaf's triangles, pop the next deferred sibling.  The lane's whole
@@ -238,25 +236,23 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                             if (h && t < w_best) { w_best = t; w_prim = start + k; }
                         }
                         RT_LAP_SPLIT_LEAF(TM_LEAF)
-                        /* pop: an entry is taken iff !(dist > best) (:501); through a collapsed chain
-                         * iff dist < best (:517) */
-                        bool found = false;
-                        while (sp > 0) {
+                        /* pop one entry: it is taken iff !(dist > best) (:501); through a
+                         * collapsed chain iff dist < best (:517) - the distance is never NaN, so
+                         * that is dist < best, or dist == best on a plain edge.  A lane whose entry
+                         * is refused stays on the empty leaf and pops again next step (rare). */
+                        if (sp > 0) {
                             RT_STAT(ST_POP);
                             sp--;
                             const uint2 e = stack[sp * NT + tid];
                             const float dd = __uint_as_float(e.x);
-                            const uint32_t rr = e.y;
-                            const bool take = (rr & RT_REF_CHAIN) ? (dd < w_best) : !(dd > w_best);
-                            if (take) { cur = rr; found = true; break; }
-                        }
-                        if (!found) {
+                            const bool take = dd < w_best || (dd == w_best && !(e.y & RT_REF_CHAIN));
+                            cur = take ? e.y : RT_REF_EMPTY_LEAF;
+                        } else {
                             RT_STAT(ST_DONE_MESH);
                             /* this mesh is done: merge (smaller distance, or equal and later in the list) */
                             if (w_prim >= 0 && (w_best < p.best_t || (w_best == p.best_t && w_obj > p.best_obj))) {
                                 p.best_t = w_best; p.best_obj = w_obj; p.best_prim = w_prim;
                             }
-                            w_active = false;
                             p.mode = p.next_mesh >= a.num_meshes ? M_SHADE : M_MESH;
                         }
                     }
