@@ -386,3 +386,20 @@ def test_random_mixed_scenes(rt, orc, ctx, models_dir, seed):
     got = hip_render(rt, ctx, objs, W, H, spp, limit, sky, time_ms=1000 + seed)
     want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(W, H).floats(), W, H, spp, limit, sky, time_ms=1000 + seed)
     assert eq(got, want)
+
+
+@pytest.mark.parametrize("name,W,H,spp,limit", [("monkey", 160, 120, 6, 8), ("cube", 96, 64, 8, 8), ("reference_scene0", 125, 100, 4, 5)])
+def test_pooled_kernel_equals_oracle(rt, orc, models_dir, monkeypatch, name, W, H, spp, limit):
+    """the opt-in workgroup ray pool (RT_AMD_POOL=1, rt_render_pool_kernel): rays change waves, the
+    image must not change.  The switch is read when a context is created."""
+    monkeypatch.setenv("RT_AMD_POOL", "1")
+    pctx = rt.Context(0)
+    objs, sky = rt.scenes.CONFIG_SCENES[name]()
+    scene = pctx.commit(rt.SceneObjects(objs))
+    assert scene.info()["lds_bytes"] > 0
+    got = hip_render(rt, pctx, objs, W, H, spp, limit, sky)
+    want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(W, H).floats(), W, H, spp, limit, sky)
+    assert eq(got, want)
+    # several frames in a row through the same context (queues and flags start clean every launch)
+    again = hip_render(rt, pctx, objs, W, H, spp, limit, sky)
+    assert eq(again, want)
