@@ -588,6 +588,25 @@ def tile_owned_rows(height, band_rows=8, band_first=0, band_stride=1):
     return lib().rt_tile_owned_rows(C.byref(ts), int(height))
 
 
+def save_png(path, image):
+    """Writes a frame as an 8-bit RGB PNG (the format of the reference's images/*.png).  `image`
+    is [H, W, 3|4] uint8, or a float frame, which is converted like the reference's display path
+    (src/main.cu:343-371: int(px * 255), clamped)."""
+    import struct
+    import zlib
+    img = np.asarray(image)
+    if img.dtype != np.uint8:
+        img = np.clip((img.astype(np.float32) * np.float32(255)).astype(np.int64), 0, 255).astype(np.uint8)
+    img = np.ascontiguousarray(img[:, :, :3])
+    h, w = img.shape[:2]
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), img.reshape(h, w * 3)], axis=1).tobytes()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 def to_rgba8_device(ctx, d_rgb, width, height, d_rgba, stream=None):
     """float -> RGBA8 of src/main.cu:343-371 on the device."""
     ctx._check(lib().rt_to_rgba8_device(ctx._h, C.c_void_p(d_rgb), int(width), int(height), C.c_void_p(d_rgba), C.c_void_p(stream or 0)))

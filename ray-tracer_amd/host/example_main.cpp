@@ -1,9 +1,10 @@
 /*
  * example_main.cpp — what the reference's main() (src/main.cu:401-432) looks like on top of
  * raytracer.hpp, minus the SFML window: build a scene with the reference's factories, render
- * progressive frames, write the float->RGBA8 result (src/main.cu:343-371) as a binary PPM.
+ * progressive frames, write the float->RGBA8 result (src/main.cu:343-371) as a binary PPM or,
+ * if the name ends in .png, as a PNG like the reference's images/*.png.
  *
- *   example_main <models_dir> <scene 0|1> <width> <height> <frames> <out.ppm>
+ *   example_main <models_dir> <scene 0|1> <width> <height> <frames> <out.ppm|out.png>
  *
  * Build:  g++ -std=c++17 -O2 example_main.cpp -L.. -lraytracer_amd -Wl,-rpath,'$ORIGIN/..'
  */
@@ -18,7 +19,7 @@ using namespace rtamd;
 int main(int argc, char **argv)
 {
     if (argc < 7) {
-        std::fprintf(stderr, "usage: %s <models_dir> <scene 0|1> <width> <height> <frames> <out.ppm>\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <models_dir> <scene 0|1> <width> <height> <frames> <out.ppm|out.png>\n", argv[0]);
         return 2;
     }
     const std::string models = argv[1];
@@ -35,11 +36,16 @@ int main(int argc, char **argv)
             std::printf("frame %d: %.2f ms\n", data.frame_num, renderer.last_kernel_ms());
         }
         std::vector<uint8_t> rgba = parse_pixel_colours(data.previous_render, W, H);
-        FILE *fp = std::fopen(argv[6], "wb");
-        if (!fp) throw std::runtime_error("cannot open output file");
-        std::fprintf(fp, "P6\n%d %d\n255\n", W, H);
-        for (size_t i = 0; i < (size_t)W * (size_t)H; i++) std::fwrite(&rgba[4 * i], 1, 3, fp);
-        std::fclose(fp);
+        const std::string out = argv[6];
+        if (out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0) {
+            write_png(out, rgba, W, H);
+        } else {
+            FILE *fp = std::fopen(out.c_str(), "wb");
+            if (!fp) throw std::runtime_error("cannot open output file");
+            std::fprintf(fp, "P6\n%d %d\n255\n", W, H);
+            for (size_t i = 0; i < (size_t)W * (size_t)H; i++) std::fwrite(&rgba[4 * i], 1, 3, fp);
+            std::fclose(fp);
+        }
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -16,6 +16,7 @@
 #define RAYTRACER_AMD_HPP
 
 #include <cstdint>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -324,6 +325,64 @@ inline std::vector<uint8_t> parse_pixel_colours(const std::vector<float> &pixel_
         out[4 * i + 3] = 255;
     }
     return out;
+}
+
+/* What the reference shows in its SFML window (src/main.cu:374-386) written to a file instead:
+ * an 8-bit RGB PNG (the format of the reference's images/*.png) without any library - zlib
+ * "stored" blocks, so the file is W*H*3 bytes plus headers. */
+inline void write_png(const std::string &path, const std::vector<uint8_t> &rgba, int width, int height)
+{
+    auto crc32 = [](const uint8_t *p, size_t n, uint32_t crc) {
+        crc = ~crc;
+        for (size_t i = 0; i < n; i++) {
+            crc ^= p[i];
+            for (int k = 0; k < 8; k++) crc = (crc >> 1) ^ (0xedb88320u & (0u - (crc & 1u)));
+        }
+        return ~crc;
+    };
+    auto be32 = [](std::vector<uint8_t> &v, uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((uint8_t)(x >> s)); };
+    /* raw scanlines: filter byte 0 + RGB */
+    std::vector<uint8_t> raw;
+    raw.reserve((size_t)height * ((size_t)width * 3 + 1));
+    for (int y = 0; y < height; y++) {
+        raw.push_back(0);
+        for (int x = 0; x < width; x++) {
+            const uint8_t *px = &rgba[4 * ((size_t)y * (size_t)width + (size_t)x)];
+            raw.push_back(px[0]); raw.push_back(px[1]); raw.push_back(px[2]);
+        }
+    }
+    /* zlib stream of stored deflate blocks (at most 65535 bytes each) + adler32 */
+    std::vector<uint8_t> z = {0x78, 0x01};
+    uint32_t a = 1, b = 0;
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        const size_t n = raw.size() - off < 65535 ? raw.size() - off : 65535;
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 255)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 255)); z.push_back((uint8_t)((~n >> 8) & 255));
+        z.insert(z.end(), raw.begin() + (std::ptrdiff_t)off, raw.begin() + (std::ptrdiff_t)(off + n));
+        for (size_t i = off; i < off + n; i++) { a = (a + raw[i]) % 65521u; b = (b + a) % 65521u; }
+        if (n == 0) break;
+    }
+    be32(z, (b << 16) | a);
+    std::vector<uint8_t> file = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    auto chunk = [&](const char *type, const std::vector<uint8_t> &data) {
+        be32(file, (uint32_t)data.size());
+        const size_t start = file.size();
+        file.insert(file.end(), type, type + 4);
+        file.insert(file.end(), data.begin(), data.end());
+        be32(file, crc32(&file[start], file.size() - start, 0));
+    };
+    std::vector<uint8_t> ihdr;
+    be32(ihdr, (uint32_t)width); be32(ihdr, (uint32_t)height);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);   /* 8-bit RGB */
+    chunk("IHDR", ihdr);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+    FILE *fp = std::fopen(path.c_str(), "wb");
+    if (!fp) throw std::runtime_error("cannot open output file");
+    const bool ok = std::fwrite(file.data(), 1, file.size(), fp) == file.size();
+    std::fclose(fp);
+    if (!ok) throw std::runtime_error("cannot write output file");
 }
 
 }  // namespace rtamd

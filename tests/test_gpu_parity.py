@@ -239,12 +239,16 @@ def test_cpp_host_mirror_end_to_end(rt, orc, models_dir, tmp_path):
     exe = bmod.build_example()
     W, H, frames = 80, 64, 2
     for scene_num, name in ((1, "reference_scene1"), (0, "reference_scene0")):
-        out = tmp_path / ("s%d.ppm" % scene_num)
+        out = tmp_path / ("s%d.%s" % (scene_num, "png" if scene_num == 1 else "ppm"))
         subprocess.check_call([exe, models_dir, str(scene_num), str(W), str(H), str(frames), str(out)], timeout=300)
-        raw = out.read_bytes()
-        header = ("P6\n%d %d\n255\n" % (W, H)).encode()
-        assert raw.startswith(header)
-        got = np.frombuffer(raw[len(header):], np.uint8).reshape(H, W, 3)
+        if scene_num == 1:
+            from test_png import decode_png
+            got = decode_png(out)
+        else:
+            raw = out.read_bytes()
+            header = ("P6\n%d %d\n255\n" % (W, H)).encode()
+            assert raw.startswith(header)
+            got = np.frombuffer(raw[len(header):], np.uint8).reshape(H, W, 3)
         objs, sky = rt.scenes.CONFIG_SCENES[name]()
         o = orc.Scene(objs, orc.MATH_DET, models_dir)
         prev = None
