@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 #define N 4096
 __global__ void k_dep(float *out, unsigned long long *cyc, float x)
 {
@@ -71,6 +72,33 @@ __global__ void k_node(float *out, unsigned long long *cyc, int active)
     }
     out[threadIdx.x] = acc + idx;
 }
+// the same 64 bytes fetched as N reads of W bytes: is the cost per instruction or per byte?
+template <int W>
+__global__ void k_node_w(float *out, unsigned long long *cyc, int active)
+{
+    __shared__ v4f lds[2048];
+    for (int i = threadIdx.x; i < 2048; i += 64) {
+        unsigned nxt = (unsigned)(((i * 1103515245u + 12345u) >> 7) & 2047 & ~3);
+        v4f v; v.x = i; v.y = 1; v.z = 2; v.w = __uint_as_float(nxt); lds[i] = v;
+    }
+    __syncthreads();
+    unsigned idx = (threadIdx.x * 4) & 2047; float acc = 0;
+    if ((int)threadIdx.x < active) {
+        unsigned long long t0 = __builtin_readcyclecounter();
+        for (int i = 0; i < 1024; i++) {
+            const volatile float *f = (const volatile float *)&lds[idx];
+            float last = 0;
+            if (W == 4) { for (int k = 0; k < 16; k++) { float v = f[k]; acc += v; last = v; } }
+            else if (W == 8) { const v2f *g = (const v2f *)&lds[idx]; v2f v0 = g[0], v1 = g[1], v2 = g[2], v3 = g[3], v4 = g[4], v5 = g[5], v6 = g[6], v7 = g[7]; acc += v0.x + v1.x + v2.x + v3.x + v4.x + v5.x + v6.x; last = v7.y; }
+            else if (W == 48) { v4f a = lds[idx], b = lds[idx + 1], c = lds[idx + 2]; v2f d = ((const v2f *)&lds[idx + 3])[1]; acc += a.x + b.y + c.z; last = d.y; }
+            else if (W == 32) { v4f a = lds[idx], d = lds[idx + 3]; acc += a.x; last = d.w; }      // only 2 of the 4 quads
+            idx = __float_as_uint(last) & ~3u;
+        }
+        unsigned long long t1 = __builtin_readcyclecounter();
+        if (threadIdx.x == 0) cyc[0] = t1 - t0;
+    }
+    out[threadIdx.x] = acc + idx;
+}
 __global__ void k_salu(float *out, unsigned long long *cyc, int x)
 {
     int a = x;
@@ -96,5 +124,9 @@ int main()
     RUN(k_node, 1024.0, out, cyc, 64)
     RUN(k_node, 1024.0, out, cyc, 16)
     RUN(k_node, 1024.0, out, cyc, 4)
+    RUN(k_node_w<4>, 1024.0, out, cyc, 64)
+    RUN(k_node_w<8>, 1024.0, out, cyc, 64)
+    RUN(k_node_w<48>, 1024.0, out, cyc, 64)
+    RUN(k_node_w<32>, 1024.0, out, cyc, 64)
     return 0;
 }

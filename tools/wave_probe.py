@@ -32,6 +32,8 @@ tn = ["CTL", "SHADE", "FETCH", "GEN", "MESH", "DESCEND", "LEAF", "POP"]
 t = [buf[24 + i] for i in range(8)]
 waves, life = buf[33], buf[32]
 tot = float(sum(t))
+if tot == 0:
+    sys.exit(0)          # not a -DRT_STATS build: only the kernel time is meaningful
 print("  waves %d, mean wave lifetime %.2f ms; timer total %.3e ticks (%.1f ticks per us of lifetime)" % (waves, life / max(waves, 1) * 1e-5, tot, tot / max(life * 1e-2, 1e-9)))
 for n, v in zip(tn, t):
     print("    %-8s %5.1f%%" % (n, 100.0 * v / tot))
