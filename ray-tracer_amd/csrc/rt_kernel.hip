@@ -129,9 +129,22 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
     for (;;) {
         RT_STAT(ST_ITER);
         RT_LAP(TM_CTL);
-        if (p.mode == M_SHADE) {
-            RT_STAT(ST_SHADE);
-            px_shade(p, a, f, L);
+        /* A ray that hit nothing costs a handful of instructions (sky, end of sample): it is
+         * finished on the spot and the lane generates its next ray in this same round.  Hits
+         * (several hundred instructions: three Box-Muller draws, four normalisations) are shaded
+         * in batches: without a mesh the lanes holding one wait until `shade_batch` of them
+         * do, or nobody else can move, while the others go on generating; with a mesh the
+         * traversal loop below already yields in batches (`ready_break`). */
+        if (p.mode == M_SHADE && p.best_obj < 0) px_shade_miss(p, a, f);
+        {
+            const int n_hit = __popcll(__ballot(p.mode == M_SHADE));
+            const bool others = __ballot(p.mode == M_GEN || (p.mode == M_FETCH && !ch.exhausted)) != 0ull;
+            if (n_hit > 0 && (HAS_MESH || n_hit >= a.shade_batch || !others)) {
+                if (p.mode == M_SHADE) {
+                    RT_STAT(ST_SHADE);
+                    px_shade(p, a, f, L);
+                }
+            }
         }
         RT_LAP(TM_SHADE);
         px_fetch(p, ch, a, f, lane);
@@ -454,6 +467,7 @@ __global__ __launch_bounds__(NT) void rt_render_pool_kernel(const rt_kernel_args
         /* ---- the pixels' own work, once enough lanes want it (or there is nothing else to do) */
         if (n_ready >= thr || (n_ready > 0 && n_node + n_leaf <= 0)) {
             idle_since = 0;
+            if (p.mode == M_SHADE && p.best_obj < 0) px_shade_miss(p, a, f);
             if (p.mode == M_SHADE) {
                 RT_STAT(ST_SHADE);
                 px_shade(p, a, f, L);

@@ -165,16 +165,50 @@ __device__ __forceinline__ void frame_init(Frame &f, const rt_kernel_args &a)
     f.tiles_per_band = a.tiles_x * (a.band_rows >> 3);
 }
 
-/* ================= SHADE: the closest hit of this bounce is known ======================== */
+/* the end of a sample (src/raytracer.cu:102-112, :133-135): add it to the pixel, restart from a
+ * copy of the primary ray, and after the last sample blend with the previous frame and store */
+__device__ __forceinline__ void px_end_sample(Px &p, const rt_kernel_args &a, const Frame &f)
+{
+    /* src/raytracer.cu:102-105: the next sample restarts from a copy of the primary ray */
+    p.colour = p.colour + p.fin;
+    p.sample++;
+    p.fin = v3(0.f, 0.f, 0.f); p.thr = v3(1.f, 1.f, 1.f);
+    p.o = f.cam_pos; p.d = p.primary; p.bounce = 0; p.cur_n = 1.0f;
+    if (p.sample >= f.spp) {
+        /* src/raytracer.cu:107-112 and :133-135 */
+        const int array_index = (p.py * f.W + p.px) * 3;
+        V3 c = p.colour / (float)f.spp;
+        V3 previous = v3(0.f, 0.f, 0.f);
+        if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
+        V3 previous_sum = previous * (float)a.frame_num;
+        V3 res = (c + previous_sum) / (float)(a.frame_num + 1);
+        int out_row = p.py;
+        if (a.compact) {
+            const int band = p.py / a.band_rows;
+            out_row = ((band - a.band_first) / a.band_stride) * a.band_rows + (p.py - band * a.band_rows);
+        }
+        float *dst = a.out + ((size_t)out_row * (size_t)f.W + (size_t)p.px) * 3;
+#ifdef RT_COSTMAP
+        res = v3(__uint_as_float(RT_COSTMAP == 2 ? p.c_wsteps : p.c_steps), __uint_as_float(p.c_t0), __uint_as_float((unsigned)wall_clock64()));
+#endif
+        dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+        p.mode = M_FETCH;
+    }
+}
+
+/* ================= SHADE, a ray that hit nothing (src/raytracer.cu:76-80): sky, end of sample == */
+__device__ __forceinline__ void px_shade_miss(Px &p, const rt_kernel_args &a, const Frame &f)
+{
+    p.fin = p.fin + f.sky * p.thr;
+    p.mode = M_GEN;
+    px_end_sample(p, a, f);
+}
+
+/* ================= SHADE: the closest hit of this bounce is known (p.best_obj >= 0) ========= */
 __device__ __forceinline__ void px_shade(Px &p, const rt_kernel_args &a, const Frame &f, const Lds &L)
 {
     V3 &o = p.o, &d = p.d;
-    bool end_sample;
-    if (p.best_obj < 0) {
-        /* src/raytracer.cu:76-80 */
-        p.fin = p.fin + f.sky * p.thr;
-        end_sample = true;
-    } else {
+    {
         const int best_obj = p.best_obj, best_prim = p.best_prim;
         const v4f ma = L.objs[RT_OBJLDS_F4 * best_obj], mb = L.objs[RT_OBJLDS_F4 * best_obj + 1];
         const uint32_t packed = __float_as_uint(mb.w);
@@ -284,36 +318,9 @@ __device__ __forceinline__ void px_shade(Px &p, const rt_kernel_args &a, const F
             p.thr = p.thr * tc;
         }
         p.bounce++;
-        end_sample = p.bounce >= f.limit;
     }
     p.mode = M_GEN;
-    if (end_sample) {
-        /* src/raytracer.cu:102-105: the next sample restarts from a copy of the primary ray */
-        p.colour = p.colour + p.fin;
-        p.sample++;
-        p.fin = v3(0.f, 0.f, 0.f); p.thr = v3(1.f, 1.f, 1.f);
-        o = f.cam_pos; d = p.primary; p.bounce = 0; p.cur_n = 1.0f;
-        if (p.sample >= f.spp) {
-            /* src/raytracer.cu:107-112 and :133-135 */
-            const int array_index = (p.py * f.W + p.px) * 3;
-            V3 c = p.colour / (float)f.spp;
-            V3 previous = v3(0.f, 0.f, 0.f);
-            if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
-            V3 previous_sum = previous * (float)a.frame_num;
-            V3 res = (c + previous_sum) / (float)(a.frame_num + 1);
-            int out_row = p.py;
-            if (a.compact) {
-                const int band = p.py / a.band_rows;
-                out_row = ((band - a.band_first) / a.band_stride) * a.band_rows + (p.py - band * a.band_rows);
-            }
-            float *dst = a.out + ((size_t)out_row * (size_t)f.W + (size_t)p.px) * 3;
-#ifdef RT_COSTMAP
-            res = v3(__uint_as_float(RT_COSTMAP == 2 ? p.c_wsteps : p.c_steps), __uint_as_float(p.c_t0), __uint_as_float((unsigned)wall_clock64()));
-#endif
-            dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-            p.mode = M_FETCH;
-        }
-    }
+    if (p.bounce >= f.limit) px_end_sample(p, a, f);
 }
 
 /* ================= FETCH: lanes without a pixel take the next ones =========================
