@@ -44,6 +44,7 @@ struct rt_ctx {
     int descend_keep = 24;       /* RT_AMD_DESCEND_KEEP (0..64): 0 = run every descent to its end */
     int tile_scatter = 1;        /* RT_AMD_TILE_SCATTER=0: hand tiles out in raster order */
     int ready_break = 24;        /* lanes; RT_AMD_READY_BREAK overrides; 65 = never */
+    int hit_break = 24;          /* lanes; RT_AMD_HIT_BREAK */
     int shade_batch = 40;        /* lanes; RT_AMD_SHADE_BATCH (1..64) */
     int use_pool = 0;            /* RT_AMD_POOL=1: mesh scenes through the workgroup ray pool (rt_render_pool_kernel); an experiment, slower */
     int pool_fill = 16, pool_low = 16, pool_leaf_batch = 48;    /* RT_AMD_POOL_FILL / _LOW / _LEAF_BATCH */
@@ -118,6 +119,7 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (const char *e = getenv("RT_AMD_DESCEND_KEEP")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->descend_keep = v; }
     if (const char *e = getenv("RT_AMD_TILE_SCATTER")) ctx->tile_scatter = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_HEAVY_FIRST")) ctx->heavy_first = atoi(e) != 0;
+    if (const char *e = getenv("RT_AMD_HIT_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->hit_break = v; }
     if (const char *e = getenv("RT_AMD_SHADE_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->shade_batch = v; }
     if (const char *e = getenv("RT_AMD_POOL")) ctx->use_pool = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_POOL_FILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->pool_fill = v; }
@@ -375,6 +377,7 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     a.stack_entries = scene->flat.stack_entries;
     a.work_threshold = ctx->work_threshold;
     a.ready_break = ctx->ready_break;
+    a.hit_break = ctx->hit_break;
     a.shade_batch = ctx->shade_batch;
     a.pool_fill = ctx->pool_fill;
     a.pool_low = ctx->pool_low;

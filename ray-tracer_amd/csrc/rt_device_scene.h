@@ -112,6 +112,7 @@ typedef struct {
     int32_t work_threshold;        /* run traversal steps while at least this many lanes traverse */
     int32_t descend_keep;          /* leave the descend loop when fewer than descend_keep/64 of its lanes remain */
     int32_t ready_break;           /* ... unless at least this many lanes are ready to shade / generate */
+    int32_t hit_break;             /* ... or this many hold a hit to shade */
     int32_t shade_batch;           /* scenes without a mesh: hits are shaded once this many lanes hold one */
     /* pooled kernel */
     int32_t pool_fill;             /* a box-test executor hands on / takes on rays once this many of its lanes are not stepping */

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
         {
             const int n_hit = __popcll(__ballot(p.mode == M_SHADE));
             const bool others = __ballot(p.mode == M_GEN || (p.mode == M_FETCH && !ch.exhausted)) != 0ull;
-            if (n_hit > 0 && (HAS_MESH || n_hit >= a.shade_batch || !others)) {
+            const int n_trav = __popcll(__ballot(p.mode == M_WAIT));
+            if (n_hit > 0 && (HAS_MESH ? (n_hit >= a.hit_break || n_trav < a.work_threshold) : (n_hit >= a.shade_batch || !others))) {
                 if (p.mode == M_SHADE) {
                     RT_STAT(ST_SHADE);
                     px_shade(p, a, f, L);
@@ -184,8 +185,12 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
             for (;;) {
                 const int n_active = __popcll(__ballot(p.mode == M_WAIT));
                 if (n_active == 0) break;
-                const int n_ready = __popcll(__ballot(p.mode != M_WAIT && p.mode != M_DONE));
-                if (n_ready > 0 && (n_active < a.work_threshold || n_ready >= a.ready_break)) break;
+                /* lanes holding a hit wait for a batch of `hit_break`; the cheap kinds of ready
+                 * lane (generate, fetch, next mesh, a miss) for one of `ready_break` */
+                const bool is_hit = p.mode == M_SHADE && p.best_obj >= 0;
+                const int n_hit = __popcll(__ballot(is_hit));
+                const int n_light = __popcll(__ballot(p.mode != M_WAIT && p.mode != M_DONE && !is_hit));
+                if (n_hit + n_light > 0 && (n_active < a.work_threshold || n_hit >= a.hit_break || n_light >= a.ready_break)) break;
 #if defined(RT_COSTMAP) && RT_COSTMAP == 2
                 p.c_wsteps += 1;      /* wave-level macro steps this lane lived through */
 #endif

@@ -1,6 +1,6 @@
 """Critical-path probe (development tool): times rank 0's share of an 8-GPU run (one tile per
 wave, so the time is the most expensive tile's) and the full frame, for threshold settings
-"work_threshold:ready_break" given on the command line."""
+"work_threshold:ready_break[:descend_keep[:hit_break]]" given on the command line."""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,8 @@ ctxs = []
 for s in sets:
     parts = s.split(":")
     os.environ["RT_AMD_WORK_THRESHOLD"], os.environ["RT_AMD_READY_BREAK"] = parts[0], parts[1]
-    os.environ["RT_AMD_DESCEND_KEEP"] = parts[2] if len(parts) > 2 else "0"
+    os.environ["RT_AMD_DESCEND_KEEP"] = parts[2] if len(parts) > 2 else "24"
+    os.environ["RT_AMD_HIT_BREAK"] = parts[3] if len(parts) > 3 else "24"
     c = rt.Context(0)
     ctxs.append((c, c.commit(rt.SceneObjects(objs))))
 res = {s: ([], []) for s in sets}
