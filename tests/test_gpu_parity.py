@@ -285,8 +285,9 @@ def test_bench_two_ranks_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["scaling"] == "weak" and j["config"]["image"] == "2720x1530" and j["gathered_equals_single_launch"] is True
-    assert j["gathered_equals_single_launch"] is True
     assert "roofline" in j and j["roofline"]["bound"] == "hbm"
+    # ... and the weak-scaling line also carries the strong-scaling time of the 1920x1080 frame
+    assert j["strong_scaling"]["image"] == "1920x1080" and j["strong_scaling"]["value"] > 0
 
 
 def test_textured_and_refractive_primitives(rt, orc, ctx, models_dir):
