@@ -408,3 +408,14 @@ def test_pooled_kernel_equals_oracle(rt, orc, models_dir, monkeypatch, name, W, 
     # several frames in a row through the same context (queues and flags start clean every launch)
     again = hip_render(rt, pctx, objs, W, H, spp, limit, sky)
     assert eq(again, want)
+
+
+@pytest.mark.parametrize("name", ["monkey", "three_sphere"])
+def test_tiny_and_thin_images(rt, orc, ctx, models_dir, name):
+    """images smaller than one tile, one pixel wide or high, one pixel in total"""
+    objs, sky = rt.scenes.CONFIG_SCENES[name]()
+    o = orc.Scene(objs, orc.MATH_DET, models_dir)
+    for W, H, spp, limit in ((1, 1, 3, 8), (7, 3, 2, 4), (8, 8, 1, 1), (9, 17, 2, 8), (64, 1, 2, 3), (1, 40, 2, 3), (130, 5, 1, 8)):
+        got = hip_render(rt, ctx, objs, W, H, spp, limit, sky, time_ms=777)
+        want = o.render(rt.Camera(W, H).floats(), W, H, spp, limit, sky, time_ms=777)
+        assert eq(got, want), (W, H)
