@@ -219,11 +219,9 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                             const v4f *n = L.nodes + 4 * (int)(cur & RT_REF_NODE_MASK);
                             v4f q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
                             float ld, rdist;
-                            const bool lh = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, ld);
-                            const bool rh2 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, rdist);
+                            const bool l_push = box_enter(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, w_best, ld);
+                            const bool r_push = box_enter(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, w_best, rdist);
                             const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
-                            const bool l_push = lh && ld < w_best;
-                            const bool r_push = rh2 && rdist < w_best;
                             const bool l_first = ld < rdist;
                             /* Of two entered children the one pushed first (left when l_first) is
                              * visited second: it is the deferred sibling.  The other is popped
