@@ -2,7 +2,7 @@
  * example_main.cpp — what the reference's main() (src/main.cu:401-432) looks like on top of
  * raytracer.hpp, minus the SFML window: build a scene with the reference's factories, render
  * progressive frames, write the float->RGBA8 result (src/main.cu:343-371) as a binary PPM or,
- * if the name ends in .png, as a PNG like the reference's images/*.png.
+ * if the name ends in .png, as a PNG like the reference's images/ directory.
  *
  *   example_main <models_dir> <scene 0|1> <width> <height> <frames> <out.ppm|out.png>
  *

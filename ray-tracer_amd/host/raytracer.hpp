@@ -328,7 +328,7 @@ inline std::vector<uint8_t> parse_pixel_colours(const std::vector<float> &pixel_
 }
 
 /* What the reference shows in its SFML window (src/main.cu:374-386) written to a file instead:
- * an 8-bit RGB PNG (the format of the reference's images/*.png) without any library - zlib
+ * an 8-bit RGB PNG (the format of the reference's images/ directory) without any library - zlib
  * "stored" blocks, so the file is W*H*3 bytes plus headers. */
 inline void write_png(const std::string &path, const std::vector<uint8_t> &rgba, int width, int height)
 {
