@@ -179,6 +179,18 @@ typedef struct rt_tile_spec {
 rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
                            int32_t time_ms, int32_t frame_num, const rt_tile_spec *tiles,
                            const float *d_prev, float *d_out, void *hip_stream);
+
+/* n_frames (1..16) consecutive progressive frames of one view in ONE launch: what the reference's main
+ * loop (src/main.cu:415-431) does with one render() per frame - frames frame_num, frame_num + 1, ...,
+ * seeded with times_ms[0..n_frames) - accumulated IN PLACE in d_frame (same layout as d_out above; when
+ * frame_num > 0 its content is the image after frame_num - 1, otherwise it is ignored).  The result is
+ * bit-identical to n_frames rt_render_device calls.  Every frame has its own random stream, so frame
+ * k + 1 of a pixel is traced while the expensive pixels of frame k are still running; only the final
+ * blend of a pixel waits for its previous frame (a per-pixel counter in HBM).  A launch per frame leaves
+ * most of the GPU idle while the few most expensive tiles finish. */
+rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
+                                 const int32_t *times_ms, int32_t n_frames, int32_t frame_num, const rt_tile_spec *tiles,
+                                 float *d_frame, void *hip_stream);
 /* number of rows a rank owns under a tile spec (host helper for sizing compact buffers) */
 int32_t rt_tile_owned_rows(const rt_tile_spec *tiles, int32_t height);
 

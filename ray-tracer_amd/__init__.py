@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
     "rt_obj_num_vertices", "rt_obj_num_faces", "rt_obj_face_arity", "rt_obj_get_face", "rt_obj_from_arrays", "rt_obj_get_vertices",
     "rt_obj_num_triangles", "rt_obj_get_triangles", "rt_camera_default", "rt_camera_make",
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_commit", "rt_scene_destroy",
-    "rt_scene_get_info", "rt_render", "rt_render_device", "rt_tile_owned_rows", "rt_last_kernel_ms",
+    "rt_scene_get_info", "rt_render", "rt_render_device", "rt_render_device_batch", "rt_tile_owned_rows", "rt_last_kernel_ms",
     "rt_to_rgba8_device", "rt_debug_flatten", "rt_debug_read_stats", "rt_debug_eval", "rt_version",
 ]
 
@@ -157,6 +157,8 @@ def lib():
     L.rt_render.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.c_int32, C.POINTER(C.c_int32), fp]
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.c_int32, C.c_int32,
                                    C.POINTER(rt_tile_spec), vp, vp, vp]
+    L.rt_render_device_batch.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+                                         C.POINTER(rt_tile_spec), vp, vp]
     L.rt_tile_owned_rows.argtypes = [C.POINTER(rt_tile_spec), C.c_int32]
     L.rt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.rt_to_rgba8_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
@@ -573,6 +575,16 @@ def render_device(ctx, scene, camera, render_data, time_ms, frame_num, d_out, d_
     ts = rt_tile_spec(int(band_rows), int(band_first), int(band_stride), int(bool(compact)))
     ctx._check(lib().rt_render_device(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), int(time_ms), int(frame_num),
                                       C.byref(ts), C.c_void_p(d_prev or 0), C.c_void_p(d_out), C.c_void_p(stream or 0)))
+
+
+def render_device_batch(ctx, scene, camera, render_data, times_ms, frame_num, d_frame,
+                        band_rows=8, band_first=0, band_stride=1, compact=False, stream=None):
+    """len(times_ms) consecutive progressive frames in ONE launch, accumulated in place in the device
+    buffer d_frame (bit-identical to that many render_device calls; see rt_render_device_batch)."""
+    ts = rt_tile_spec(int(band_rows), int(band_first), int(band_stride), int(bool(compact)))
+    t = (C.c_int32 * len(times_ms))(*[int(x) for x in times_ms])
+    ctx._check(lib().rt_render_device_batch(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), t, len(times_ms), int(frame_num),
+                                            C.byref(ts), C.c_void_p(d_frame), C.c_void_p(stream or 0)))
 
 
 def debug_eval(ctx, op, bits):

@@ -37,6 +37,8 @@ struct rt_ctx {
     size_t frame_bytes = 0;
     /* cached tile order (longest-job-first heuristic) for the last (scene, camera, tile spec) */
     uint32_t *d_tile_order = nullptr;
+    uint32_t *d_done = nullptr;          /* multi-frame launches: frames stored per pixel */
+    size_t done_cap = 0;
     size_t tile_order_cap = 0;
     std::vector<uint32_t> order_key;     /* what the cached order was built for */
     int heavy_first = 1;                 /* RT_AMD_HEAVY_FIRST=0 disables */
@@ -143,6 +145,7 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     if (ctx->d_prev) (void)hipFree(ctx->d_prev);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
+    if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;
@@ -259,9 +262,11 @@ extern "C" int32_t rt_tile_owned_rows(const rt_tile_spec *t, int32_t height)
     return owned * t->band_rows;
 }
 
-extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
-                                      int32_t time_ms, int32_t frame_num, const rt_tile_spec *tiles,
-                                      const float *d_prev, float *d_out, void *hip_stream)
+/* one launch rendering n_frames consecutive progressive frames (n_frames == 1: a plain frame with an
+ * optional separate previous frame; > 1: d_out is updated in place) */
+static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
+                               const int32_t *times_ms, int32_t n_frames, int32_t frame_num, const rt_tile_spec *tiles,
+                               const float *d_prev, float *d_out, void *hip_stream, bool in_place)
 {
     if (!ctx || !scene || !cam || !rs || !d_out) return set_err(ctx, RT_ERR_INVALID, "null argument");
     if (scene->ctx != ctx) return set_err(ctx, RT_ERR_INVALID, "scene belongs to another context");
@@ -286,7 +291,8 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     a.reflection_limit = rs->reflection_limit;
     a.antialias = rs->antialias ? 1 : 0;
     std::memcpy(a.sky, rs->sky_colour, 12);
-    a.seed_time = (uint32_t)time_ms * 6291469u;       /* src/raytracer.cu:127 */
+    for (int i = 0; i < n_frames; i++) a.seeds[i] = (uint32_t)times_ms[i] * 6291469u;       /* src/raytracer.cu:127 */
+    a.num_frames = n_frames;
     a.frame_num = frame_num;
     a.band_rows = t->band_rows;
     a.band_first = t->band_first;
@@ -390,6 +396,18 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     a.tile_counter = ctx->tile_counter;
     a.stats = (unsigned long long *)(ctx->tile_counter + 16);   /* 48 x u64 after the counter; used by -DRT_STATS builds only */
 
+    if (in_place) {
+        const size_t px_count = (size_t)(a.compact ? owned_rows : cam->height) * (size_t)cam->width;
+        if (ctx->done_cap < px_count) {
+            if (ctx->d_done) (void)hipFree(ctx->d_done);
+            ctx->d_done = nullptr;
+            ctx->done_cap = 0;
+            RT_HIP(ctx, hipMalloc((void **)&ctx->d_done, px_count * 4), "allocating per-pixel frame counters");
+            ctx->done_cap = px_count;
+        }
+        RT_HIP(ctx, hipMemsetAsync(ctx->d_done, 0, px_count * 4, stream), "clearing per-pixel frame counters");
+        a.pixel_done = ctx->d_done;
+    }
     RT_HIP(ctx, hipEventRecord(ctx->ev_start, stream), "recording start event");
     ctx->have_timing = false;
     if (a.num_tiles > 0) {
@@ -412,6 +430,28 @@ extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const 
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream), "recording stop event");
     ctx->have_timing = true;
     return RT_OK;
+}
+
+extern "C" rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
+                                      int32_t time_ms, int32_t frame_num, const rt_tile_spec *tiles,
+                                      const float *d_prev, float *d_out, void *hip_stream)
+{
+    return render_frames(ctx, scene, cam, rs, &time_ms, 1, frame_num, tiles, d_prev, d_out, hip_stream, false);
+}
+
+/* n_frames consecutive progressive frames (frame_num, frame_num + 1, ...; seeds times_ms[i]) in ONE
+ * launch, accumulated in place in d_frame (layout of rt_render_device's d_out; its content is the
+ * previous frame when frame_num > 0, ignored otherwise).  The result is bit-identical to n_frames
+ * calls of rt_render_device; the point is that frame k + 1 is traced while the expensive pixels of
+ * frame k are still running, which a launch per frame cannot do. */
+extern "C" rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
+                                            const int32_t *times_ms, int32_t n_frames, int32_t frame_num, const rt_tile_spec *tiles,
+                                            float *d_frame, void *hip_stream)
+{
+    if (!times_ms || n_frames < 1 || n_frames > RT_MAX_BATCH_FRAMES) return set_err(ctx, RT_ERR_INVALID, "n_frames must be 1..16");
+    if (frame_num < 0) return set_err(ctx, RT_ERR_INVALID, "bad frame number");
+    if (scene && scene->pool) return set_err(ctx, RT_ERR_UNSUPPORTED, "multi-frame launches are not available with RT_AMD_POOL=1");
+    return render_frames(ctx, scene, cam, rs, times_ms, n_frames, frame_num, tiles, nullptr, d_frame, hip_stream, true);
 }
 
 /* test hook: evaluates one function of rt_math.h / rt_rng.h on the DEVICE for n inputs given

@@ -30,6 +30,7 @@
 
 #define RT_BVH_DEPTH 10              /* reference src/objects.cu:786 */
 #define RT_STACK_ENTRIES RT_BVH_DEPTH /* at most one pending sibling per level below the root */
+#define RT_MAX_BATCH_FRAMES 16        /* frames one launch can render */
 #define RT_INF_F 1073741824.0f       /* reference `1 << 31 - 1` == 1 << 30, src/objects.cu:6 */
 #define RT_EPS_F 0.000001f           /* FLOAT_PRECISION_ERROR src/objects.cu:7 */
 
@@ -93,8 +94,11 @@ typedef struct {
     int32_t width, height;
     int32_t rays_per_pixel, reflection_limit, antialias;   /* RenderData src/raytracer.cu:4-12 */
     float sky[3];
-    uint32_t seed_time;            /* (uint32)time_ms * 6291469  (src/raytracer.cu:127) */
-    int32_t frame_num;
+    uint32_t seeds[RT_MAX_BATCH_FRAMES];   /* per frame of the launch: (uint32)time_ms * 6291469  (src/raytracer.cu:127) */
+    int32_t num_frames;            /* progressive frames rendered by this launch (1: a plain frame) */
+    int32_t frame_num;             /* frame_num of the first of them */
+    uint32_t *pixel_done;          /* multi-frame (in-place) launches: per pixel of `out`, how many of the frames are stored
+                                      (zeroed before the launch); NULL for a plain frame */
     /* tile assignment */
     int32_t band_rows, band_first, band_stride, compact;
     int32_t tiles_x;               /* 8x8 tiles per row of tiles */

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
     int sp = 0, w_prim = -1, w_obj = -1;
     float w_best = RT_INF_F;
     Chunk ch;
-    ch.next = 0; ch.end = 0; ch.exhausted = false;
+    ch.next = 0; ch.end = 0; ch.frame = 0; ch.exhausted = false;
 #ifdef RT_STATS
     unsigned st_exec[ST_N], st_lanes[ST_N];
     for (int i = 0; i < ST_N; i++) { st_exec[i] = 0; st_lanes[i] = 0; }
@@ -135,6 +135,8 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
          * in batches: without a mesh the lanes holding one wait until `shade_batch` of them
          * do, or nobody else can move, while the others go on generating; with a mesh the
          * traversal loop below already yields in batches (`ready_break`). */
+        /* (multi-frame launches) a finished pixel whose previous frame was not stored yet: try again */
+        if (p.mode == M_BLEND) px_finish_pixel(p, a, f);
         if (p.mode == M_SHADE && p.best_obj < 0) px_shade_miss(p, a, f);
         {
             const int n_hit = __popcll(__ballot(p.mode == M_SHADE));
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                  * lane (generate, fetch, next mesh, a miss) for one of `ready_break` */
                 const bool is_hit = p.mode == M_SHADE && p.best_obj >= 0;
                 const int n_hit = __popcll(__ballot(is_hit));
-                const int n_light = __popcll(__ballot(p.mode != M_WAIT && p.mode != M_DONE && !is_hit));
+                const int n_light = __popcll(__ballot(p.mode != M_WAIT && p.mode != M_DONE && p.mode != M_BLEND && !is_hit));
                 if (n_hit + n_light > 0 && (n_active < a.work_threshold || n_hit >= a.hit_break || n_light >= a.ready_break)) break;
 #if defined(RT_COSTMAP) && RT_COSTMAP == 2
                 p.c_wsteps += 1;      /* wave-level macro steps this lane lived through */
@@ -278,6 +280,8 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
         }
 
         if (__ballot(p.mode != M_DONE) == 0ull) break;
+        /* nothing but pixels waiting for their previous frame: give the waves that hold it the SIMD */
+        if (__ballot(p.mode != M_DONE && p.mode != M_BLEND) == 0ull) __builtin_amdgcn_s_sleep(8);
     }
     RT_STATS_FLUSH();
 }
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(NT) void rt_render_pool_kernel(const rt_kernel_args
     int w_obj = -1;             /* object index of the mesh this lane's ray is in */
     bool retired = false;       /* wave-uniform: every pixel of this wave is finished */
     Chunk ch;
-    ch.next = 0; ch.end = 0; ch.exhausted = false;
+    ch.next = 0; ch.end = 0; ch.frame = 0; ch.exhausted = false;
 #ifdef RT_STATS
     unsigned st_exec[ST_N], st_lanes[ST_N];
     for (int i = 0; i < ST_N; i++) { st_exec[i] = 0; st_lanes[i] = 0; }

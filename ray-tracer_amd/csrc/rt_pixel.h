@@ -127,7 +127,8 @@ __device__ __forceinline__ bool quad_test(const v4f *tris, int first, V3 o, V3 d
 }
 
 /* lane states of the render loop */
-enum { M_FETCH = 0, M_GEN = 1, M_MESH = 2, M_WAIT = 3, M_SHADE = 4, M_DONE = 5 };
+enum { M_FETCH = 0, M_GEN = 1, M_MESH = 2, M_WAIT = 3, M_SHADE = 4, M_DONE = 5,
+       M_BLEND = 6 /* samples done; the previous frame of this pixel (same launch) is not stored yet */ };
 
 /* per-lane pixel state (registers) */
 struct Px {
@@ -138,6 +139,7 @@ struct Px {
     float cur_n;                 /* Ray::current_refractive_index src/ray.cu:56,144 */
     float best_t;
     int best_obj, best_prim, next_mesh;
+    int frame;                   /* which frame of a multi-frame launch this pixel belongs to */
 #ifdef RT_COSTMAP
     /* development build (tools/costmap.py): the frame holds, per pixel, (own traversal steps,
      * start tick, end tick) of the 100 MHz wall clock instead of the colour */
@@ -159,6 +161,7 @@ struct Frame {
 /* wave-uniform pixel chunk: linear pixel ids [next, end) of one 8x8 tile */
 struct Chunk {
     uint32_t next, end;
+    int frame;                   /* the frame (of a multi-frame launch) the ids belong to */
     bool exhausted;
 };
 
@@ -169,7 +172,7 @@ __device__ __forceinline__ void px_init(Px &p)
     p.colour = z; p.fin = z; p.thr = z; p.o = z; p.d = z; p.inv = z; p.primary = z;
     p.sample = 0; p.bounce = 0; p.px = 0; p.py = 0;
     p.cur_n = 1.0f; p.best_t = RT_INF_F;
-    p.best_obj = -1; p.best_prim = -1; p.next_mesh = 0;
+    p.best_obj = -1; p.best_prim = -1; p.next_mesh = 0; p.frame = 0;
     RT_COST(p.c_steps = 0; p.c_t0 = 0; p.c_wsteps = 0);
 }
 
@@ -185,35 +188,69 @@ __device__ __forceinline__ void frame_init(Frame &f, const rt_kernel_args &a)
     f.tiles_per_band = a.tiles_x * (a.band_rows >> 3);
 }
 
-/* the end of a sample (src/raytracer.cu:102-112, :133-135): add it to the pixel, restart from a
- * copy of the primary ray, and after the last sample blend with the previous frame and store */
+/* A pixel's samples are done: blend with the previous frame and store (src/raytracer.cu:107-112,
+ * :133-135).
+ *
+ * Multi-frame launches (rt_kernel_args.pixel_done != NULL) render consecutive progressive frames of one
+ * view in ONE launch: every frame has its own seed, so frame k+1 of a pixel can be traced while
+ * frame k of the same pixel is still being traced by another wave - the only thing that is
+ * sequential is this blend, (c + prev * n) / (n + 1) with prev = the pixel's value after frame k.
+ * The frame buffer is updated in place and `pixel_done[pixel]` counts the frames stored so far; a
+ * lane that arrives early parks in M_BLEND (the wave goes on with its other lanes) and tries again.
+ * Waves on other XCDs do not share an L2 with this one: the pixel and its counter are written and
+ * read with agent-scope (sc1) accesses, the counter after the stores have drained
+ * (MI355X_MICROARCH.md, inter-workgroup visibility). */
+__device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, const Frame &f)
+{
+    const V3 c = p.colour / (float)f.spp;
+    int out_row = p.py;
+    if (a.compact) {
+        const int band = p.py / a.band_rows;
+        out_row = ((band - a.band_first) / a.band_stride) * a.band_rows + (p.py - band * a.band_rows);
+    }
+    const size_t pixel = (size_t)out_row * (size_t)f.W + (size_t)p.px;
+    float *dst = a.out + pixel * 3;
+    if (a.pixel_done) {
+        const int n = a.frame_num + p.frame;
+        V3 previous = v3(0.f, 0.f, 0.f);
+        if (p.frame > 0) {
+            if (__hip_atomic_load(a.pixel_done + pixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint32_t)p.frame) { p.mode = M_BLEND; return; }
+            previous.x = __hip_atomic_load(dst + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            previous.y = __hip_atomic_load(dst + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            previous.z = __hip_atomic_load(dst + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (n > 0) {
+            previous = v3(dst[0], dst[1], dst[2]);                 /* what the caller put there before the launch */
+        }
+        const V3 res = (c + previous * (float)n) / (float)(n + 1);
+        __hip_atomic_store(dst + 0, res.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, res.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 2, res.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.pixel_done + pixel, (uint32_t)(p.frame + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        p.mode = M_FETCH;
+        return;
+    }
+    const int array_index = (p.py * f.W + p.px) * 3;
+    V3 previous = v3(0.f, 0.f, 0.f);
+    if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
+    V3 previous_sum = previous * (float)a.frame_num;
+    V3 res = (c + previous_sum) / (float)(a.frame_num + 1);
+#ifdef RT_COSTMAP
+    res = v3(__uint_as_float(RT_COSTMAP == 2 ? p.c_wsteps : p.c_steps), __uint_as_float(p.c_t0), __uint_as_float((unsigned)wall_clock64()));
+#endif
+    dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+    p.mode = M_FETCH;
+}
+
+/* the end of a sample (src/raytracer.cu:102-105): add it to the pixel, restart from a copy of the
+ * primary ray; after the last sample the pixel is finished */
 __device__ __forceinline__ void px_end_sample(Px &p, const rt_kernel_args &a, const Frame &f)
 {
-    /* src/raytracer.cu:102-105: the next sample restarts from a copy of the primary ray */
     p.colour = p.colour + p.fin;
     p.sample++;
     p.fin = v3(0.f, 0.f, 0.f); p.thr = v3(1.f, 1.f, 1.f);
     p.o = f.cam_pos; p.d = p.primary; p.bounce = 0; p.cur_n = 1.0f;
-    if (p.sample >= f.spp) {
-        /* src/raytracer.cu:107-112 and :133-135 */
-        const int array_index = (p.py * f.W + p.px) * 3;
-        V3 c = p.colour / (float)f.spp;
-        V3 previous = v3(0.f, 0.f, 0.f);
-        if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
-        V3 previous_sum = previous * (float)a.frame_num;
-        V3 res = (c + previous_sum) / (float)(a.frame_num + 1);
-        int out_row = p.py;
-        if (a.compact) {
-            const int band = p.py / a.band_rows;
-            out_row = ((band - a.band_first) / a.band_stride) * a.band_rows + (p.py - band * a.band_rows);
-        }
-        float *dst = a.out + ((size_t)out_row * (size_t)f.W + (size_t)p.px) * 3;
-#ifdef RT_COSTMAP
-        res = v3(__uint_as_float(RT_COSTMAP == 2 ? p.c_wsteps : p.c_steps), __uint_as_float(p.c_t0), __uint_as_float((unsigned)wall_clock64()));
-#endif
-        dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-        p.mode = M_FETCH;
-    }
+    if (p.sample >= f.spp) px_finish_pixel(p, a, f);
 }
 
 /* ================= SHADE, a ray that hit nothing (src/raytracer.cu:76-80): sky, end of sample == */
@@ -355,18 +392,22 @@ __device__ __forceinline__ void px_fetch(Px &p, Chunk &ch, const rt_kernel_args 
     const int need = __popcll(mask);
     const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
     int taken = 0;
-    int my_id = -1;
+    int my_id = -1, my_frame = 0;
     for (;;) {
         const int avail = (int)(ch.end - ch.next);
         const int take = avail < need - taken ? avail : need - taken;
-        if (want && rank >= taken && rank < taken + take) my_id = (int)ch.next + (rank - taken);
+        if (want && rank >= taken && rank < taken + take) { my_id = (int)ch.next + (rank - taken); my_frame = ch.frame; }
         ch.next += (uint32_t)take;
         taken += take;
         if (taken == need || ch.exhausted) break;
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(a.tile_counter, 1u);
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= (uint32_t)a.num_tiles) { ch.exhausted = true; break; }
+        /* tickets run frame by frame (a single-frame launch has num_frames == 1) */
+        const uint32_t fr = t / (uint32_t)a.num_tiles;
+        if (fr >= (uint32_t)a.num_frames) { ch.exhausted = true; break; }
+        t -= fr * (uint32_t)a.num_tiles;
+        ch.frame = (int)fr;
         /* ticket -> tile through a permutation.  A pixel's samples are sequential, so the frame
          * cannot finish before its most expensive tile does; the host therefore lists the tiles
          * whose centre ray enters a mesh box first (longest-job-first), each class scattered by a
@@ -390,7 +431,8 @@ __device__ __forceinline__ void px_fetch(Px &p, Chunk &ch, const rt_kernel_args 
         /* src/raytracer.cu:123-127; Ray::set_direction_origin src/ray.cu:147-155,
          * cam_pixel_to_world src/camera.cu:24-29 */
         const int array_index = (p.py * f.W + p.px) * 3;
-        p.rng = (uint32_t)array_index * 3145739u + a.seed_time;
+        p.frame = my_frame;
+        p.rng = (uint32_t)array_index * 3145739u + a.seeds[my_frame];
         RT_COST(p.c_steps = 0; p.c_wsteps = 0; p.c_t0 = (unsigned)wall_clock64());
         V3 plane_point = f.du * (float)p.px + f.dv * (float)p.py;
         p.primary = normalised((f.tl + plane_point) - f.cam_pos);
@@ -402,14 +444,8 @@ __device__ __forceinline__ void px_fetch(Px &p, Chunk &ch, const rt_kernel_args 
         p.sample = f.limit > 0 ? 0 : f.spp;
         if (p.sample >= f.spp) {
             const float q = 0.0f / (float)f.spp;               /* NaN for spp == 0, like the reference */
-            V3 previous = v3(0.f, 0.f, 0.f);
-            if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
-            V3 res = (v3(q, q, q) + previous * (float)a.frame_num) / (float)(a.frame_num + 1);
-            int out_row = p.py;
-            if (a.compact) out_row = band_local * a.band_rows + (p.py - band * a.band_rows);
-            float *dst = a.out + ((size_t)out_row * (size_t)f.W + (size_t)p.px) * 3;
-            dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-            /* stays in M_FETCH: takes another pixel next time round */
+            p.colour = v3(q, q, q) * (float)f.spp;             /* px_finish_pixel divides by spp again: q either way */
+            px_finish_pixel(p, a, f);                          /* M_FETCH: takes another pixel next time round (or M_BLEND) */
         } else {
             p.mode = M_GEN;
         }
