@@ -5,9 +5,19 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one frame: every rank renders the 8-row bands it
-owns (band b belongs to rank b % N) of the same frame into a compact HBM buffer, then one
-gather (RCCL over xGMI) brings the bands to rank 0, which de-interleaves them.  Inputs (scene,
-camera, previous frame) are resident in HBM before the timed region; the frame stays in HBM.
+owns (band b belongs to rank b % N) of the frame into a compact HBM buffer; one gather (RCCL over
+xGMI) brings the bands to rank 0, which de-interleaves them.  Inputs (scene, camera, previous
+frame) are resident in HBM before the timed region; the frame stays in HBM.
+
+The K timed steps are K consecutive PROGRESSIVE frames of the view (frame_num 0..K-1, seeds
+12345 + i) - the reference's own main loop, src/main.cu:415-431 - rendered by one multi-frame
+launch per rank (rt_render_device_batch, at most 16 frames per launch) and gathered once: every
+sample of every frame is traced, each pixel's frames are blended in order, and the image is
+bit-identical to K launches (--check verifies it; tests/test_gpu_parity.py).  What the single
+launch buys: a frame ends with a few expensive tiles running alone for half its duration, and
+the next frame, which has its own random stream, fills the idle GPU meanwhile.  The line also
+carries "frame_by_frame" (the same K steps with one launch per step, N = 1 only), and
+--frame-by-frame makes that the measured mode.
 
 Scaling.  A pixel's samples are sequential (one RNG stream per pixel, reference
 src/raytracer.cu:127-131), so a frame cannot finish before its most expensive pixels have run
@@ -91,6 +101,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = image area grows with N (default), strong = the same WxH frame for every N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frame-by-frame", action="store_true", help="one launch + one gather per step instead of one multi-frame launch for all steps")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-gpu rehearses N ranks on ONE GPU (RCCL refuses duplicate devices)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
@@ -136,42 +147,67 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(W, H, warmup, steps):
-        """`warmup` untimed + `steps` timed frames of a W x H image over all ranks; returns the
-        wall time (max over ranks), rank 0's last gathered frame and this rank's kernel times"""
+    MAX_BATCH = 16
+
+    def measure(W, H, warmup, steps, batched):
+        """`warmup` untimed + `steps` timed steps on a W x H image over all ranks.  batched: the steps
+        are consecutive progressive frames (frame_num 0, 1, ...; seeds 12345 + i) rendered by ONE
+        launch per rank (rt_render_device_batch, at most 16 frames per launch) and gathered once at
+        the end; otherwise one launch + one gather per step (each an independent frame 0).  Returns
+        the wall time (max over ranks), rank 0's last gathered frame, this rank's per-launch kernel
+        times and how many frames each of those launches rendered."""
         cam = rt.Camera(W, H)
         local = torch.zeros((dm.max_owned_rows(H, band_rows, world), W, 3), dtype=torch.float32, device=dev)
         gathered = torch.empty((world,) + tuple(local.shape), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
-        kernel_ms = []
+        kernel_ms, frames_per_launch = [], []
 
-        def step(record):
-            rt.render_device(ctx, scene, cam, rd, 12345, 0, local.data_ptr(), band_first=rank, band_stride=world, compact=True, stream=stream)
-            frame = dm.gather_frame(local, W, H, band_rows, rank, world, dst=0, out=gathered)
-            if record:
-                kernel_ms.append(ctx.last_kernel_ms())   # HIP events on the launch stream; waits for the kernel only
+        def run(n, record):
+            if batched:
+                done = 0
+                while done < n:
+                    k = min(MAX_BATCH, n - done)
+                    rt.render_device_batch(ctx, scene, cam, rd, [12345 + done + i for i in range(k)], done, local.data_ptr(),
+                                           band_first=rank, band_stride=world, compact=True, stream=stream)
+                    if record:
+                        kernel_ms.append(ctx.last_kernel_ms())   # HIP events on the launch stream; waits for the kernel only
+                        frames_per_launch.append(k)
+                    done += k
+                return dm.gather_frame(local, W, H, band_rows, rank, world, dst=0, out=gathered)
+            frame = None
+            for _ in range(n):
+                rt.render_device(ctx, scene, cam, rd, 12345, 0, local.data_ptr(), band_first=rank, band_stride=world, compact=True, stream=stream)
+                frame = dm.gather_frame(local, W, H, band_rows, rank, world, dst=0, out=gathered)
+                if record:
+                    kernel_ms.append(ctx.last_kernel_ms())
+                    frames_per_launch.append(1)
             return frame
 
-        for _ in range(warmup):
-            step(False)
+        if warmup > 0:
+            run(warmup, False)
         fence()
         t0 = time.perf_counter()
-        frame = None
-        for _ in range(steps):
-            frame = step(True)
+        frame = run(steps, True)
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, frame, kernel_ms, cam
+        return elapsed, frame, kernel_ms, frames_per_launch, cam
 
-    elapsed, frame, kernel_ms, cam = measure(W, H, args.warmup, args.steps)
+    batched = not args.frame_by_frame
+    elapsed, frame, kernel_ms, frames_per_launch, cam = measure(W, H, args.warmup, args.steps, batched)
+    per_frame = None
+    if batched and rank == 0 and world == 1:
+        # for the record: the same number of steps with one launch per frame (what `value` was before
+        # multi-frame launches existed); not the headline value
+        f_elapsed, _, _, _, _ = measure(W, H, 0, args.steps, False)
+        per_frame = {"value": W * H * spp * args.steps / f_elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": f_elapsed / args.steps * 1e3,
+                     "note": "one launch per step"}
     strong = None
     if world > 1 and args.scaling == "weak":
-        # for the record: the SAME args.width x args.height frame cut over the N GPUs (bounded by the
-        # frame's critical path, see the module docstring); not the headline value
-        s_elapsed, _, _, _ = measure(args.width, args.height, 1, args.steps)
+        # for the record: the SAME args.width x args.height frame cut over the N GPUs; not the headline value
+        s_elapsed, _, _, _, _ = measure(args.width, args.height, 1, args.steps, batched)
         strong = {"image": "%dx%d" % (args.width, args.height), "value": args.width * args.height * spp * args.steps / s_elapsed / 1e6,
                   "unit": "Msamples/s", "ms_per_step": s_elapsed / args.steps * 1e3}
 
@@ -184,20 +220,21 @@ def main():
     for b in dm.owned_bands(H, band_rows, rank, world):
         my_pixels += (min((b + 1) * band_rows, H) - b * band_rows) * W
     avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+    avg_frames = sum(frames_per_launch) / float(len(frames_per_launch))
     flat = so.debug_flatten()
     scene_bytes = flat["blob"].nbytes + flat["objects"].nbytes
-    algo_bytes = 24.0 * my_pixels + scene_bytes
+    algo_bytes = 24.0 * my_pixels * avg_frames + scene_bytes
     achieved_gbs = algo_bytes / avg_kernel_s / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        key = "%s_%dx%d_s%d_l%d_n%d" % (args.scene, W, H, spp, limit, world)
+        key = "%s_%dx%d_s%d_l%d_n%d_f%d" % (args.scene, W, H, spp, limit, world, int(round(avg_frames)))
         traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
     roofline = {"bound": "hbm", "kernel": "rt_render_kernel", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": avg_kernel_s * 1e3,
+                "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": avg_kernel_s * 1e3, "frames_per_launch": avg_frames,
                 "note": "24 B/pixel/frame + scene once; the path is VALU/latency-bound, see 'valu'"}
 
     out = {"metric": "Msamples/sec (WxHxspp) at %dx%d, %d bounces" % (args.width, args.height, limit), "value": value, "unit": "Msamples/s",
@@ -206,18 +243,22 @@ def main():
            "config": {"workload": "%s scene, %dx%d, %d spp, %d bounces, antialias on, time_ms 12345 (BASELINE configs[%d])"
                       % (args.scene, W, H, spp, limit, {"three_sphere": 1, "cube": 2, "monkey": 3}[args.scene]),
                       "parallelism": "image bands of 8 rows interleaved over %d GPU(s) + gather to rank 0" % world,
+                      "steps": ("consecutive progressive frames (seeds 12345 + i) in one launch per rank of up to %d frames, gathered once" % MAX_BATCH) if batched
+                               else "one launch + one gather per step",
                       "image": "%dx%d" % (W, H),
                       "threads_per_block": info["threads_per_block"], "lds_bytes": info["lds_bytes"]},
            "roofline": roofline}
     if strong is not None:
         out["strong_scaling"] = strong
+    if per_frame is not None:
+        out["frame_by_frame"] = per_frame
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             cb, st = cpu_baseline(rt, objs, sky, W, H, limit, spp)
             out["cpu_baseline"] = cb
             fps = flops_per_sample(st)
-            tflops = fps * (my_pixels * spp) / avg_kernel_s / 1e12
+            tflops = fps * (my_pixels * spp * avg_frames) / avg_kernel_s / 1e12
             out["valu"] = {"achieved": tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VECTOR_PEAK_TFLOPS,
                            "algorithmic_flops_per_sample": fps,
                            "per_sample": {k: v / float(st["samples"]) for k, v in st.items() if k != "samples"}}
@@ -225,10 +266,17 @@ def main():
         if frame is not None:
             out["frame_mean"] = float(frame.mean().item())
             if args.check:
-                alone = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-                rt.render_device(ctx, scene, cam, rd, 12345, 0, alone.data_ptr(), stream=stream)
+                # rank 0 alone, one launch per frame, must give the gathered image bit for bit
+                x = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+                y = torch.empty_like(x)
+                if batched:
+                    for i in range(args.steps):
+                        rt.render_device(ctx, scene, cam, rd, 12345 + i, i, y.data_ptr(), d_prev=x.data_ptr() if i else None, stream=stream)
+                        x, y = y, x
+                else:
+                    rt.render_device(ctx, scene, cam, rd, 12345, 0, x.data_ptr(), stream=stream)
                 torch.cuda.synchronize()
-                out["gathered_equals_single_launch"] = bool(torch.equal(frame.contiguous().view(torch.int32), alone.view(torch.int32)))
+                out["gathered_equals_single_launch"] = bool(torch.equal(frame.contiguous().view(torch.int32), x.view(torch.int32)))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

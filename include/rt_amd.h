@@ -161,6 +161,10 @@ rt_status rt_scene_get_info(const rt_scene *s, rt_scene_info *out);
  * term the reference takes from the wall clock (src/main.cu:18-25). */
 rt_status rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
                     int32_t time_ms, int32_t *frame_num, float *previous_render);
+/* n_frames passes of that loop body in one call (frame i seeded with times_ms[i]); the frames are
+ * rendered by multi-frame launches (rt_render_device_batch below), the result is the same image. */
+rt_status rt_render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
+                           const int32_t *times_ms, int32_t n_frames, int32_t *frame_num, float *previous_render);
 
 /* Device-buffer form for callers that own HBM (PyTorch tensors) and streams.
  * Rows are handed out in bands of `band_rows` rows; this call renders the bands whose index b

@@ -71,7 +71,7 @@ ABI_SYMBOLS = [
     "rt_obj_num_vertices", "rt_obj_num_faces", "rt_obj_face_arity", "rt_obj_get_face", "rt_obj_from_arrays", "rt_obj_get_vertices",
     "rt_obj_num_triangles", "rt_obj_get_triangles", "rt_camera_default", "rt_camera_make",
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_commit", "rt_scene_destroy",
-    "rt_scene_get_info", "rt_render", "rt_render_device", "rt_render_device_batch", "rt_tile_owned_rows", "rt_last_kernel_ms",
+    "rt_scene_get_info", "rt_render", "rt_render_frames", "rt_render_device", "rt_render_device_batch", "rt_tile_owned_rows", "rt_last_kernel_ms",
     "rt_to_rgba8_device", "rt_debug_flatten", "rt_debug_read_stats", "rt_debug_eval", "rt_version",
 ]
 
@@ -155,6 +155,7 @@ def lib():
     L.rt_scene_destroy.restype = None
     L.rt_scene_get_info.argtypes = [vp, C.POINTER(rt_scene_info)]
     L.rt_render.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.c_int32, C.POINTER(C.c_int32), fp]
+    L.rt_render_frames.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32), fp]
     L.rt_render_device.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.c_int32, C.c_int32,
                                    C.POINTER(rt_tile_spec), vp, vp, vp]
     L.rt_render_device_batch.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
@@ -565,6 +566,19 @@ def render(ctx, scene, camera, render_data, data, current_time_ms):
     assert buf.dtype == np.float32 and buf.flags["C_CONTIGUOUS"]
     ctx._check(lib().rt_render(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), int(current_time_ms),
                                C.byref(fn), buf.ctypes.data_as(C.POINTER(C.c_float))))
+    data.frame_num = fn.value
+    return buf
+
+
+def render_frames(ctx, scene, camera, render_data, data, times_ms):
+    """len(times_ms) consecutive passes of the reference's main loop body (src/main.cu:421-424) in
+    one call: the same image as that many render() calls, rendered by multi-frame launches."""
+    fn = C.c_int32(data.frame_num)
+    buf = data.previous_render
+    assert buf.dtype == np.float32 and buf.flags["C_CONTIGUOUS"]
+    t = (C.c_int32 * len(times_ms))(*[int(x) for x in times_ms])
+    ctx._check(lib().rt_render_frames(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), t, len(times_ms),
+                                      C.byref(fn), buf.ctypes.data_as(C.POINTER(C.c_float))))
     data.frame_num = fn.value
     return buf
 

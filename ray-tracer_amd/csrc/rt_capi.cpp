@@ -518,6 +518,40 @@ extern "C" rt_status rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_came
     return RT_OK;
 }
 
+/* the same for n_frames consecutive frames at once (seeds times_ms[i]): one multi-frame launch per
+ * 16 frames; *frame_num advances by n_frames */
+extern "C" rt_status rt_render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
+                                      const int32_t *times_ms, int32_t n_frames, int32_t *frame_num, float *previous_render)
+{
+    if (!ctx || !cam || !frame_num || !previous_render || !times_ms || n_frames < 1) return set_err(ctx, RT_ERR_INVALID, "null argument");
+    if (cam->width <= 0 || cam->height <= 0) return set_err(ctx, RT_ERR_INVALID, "bad image size");
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    const size_t bytes = (size_t)cam->width * (size_t)cam->height * 3 * sizeof(float);
+    if (bytes != ctx->frame_bytes) {
+        if (ctx->d_prev) (void)hipFree(ctx->d_prev);
+        if (ctx->d_out) (void)hipFree(ctx->d_out);
+        ctx->d_prev = ctx->d_out = nullptr;
+        ctx->frame_bytes = 0;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_prev, bytes), "allocating previous-frame buffer");
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_out, bytes), "allocating frame buffer");
+        ctx->frame_bytes = bytes;
+    }
+    RT_HIP(ctx, hipMemcpy(ctx->d_out, previous_render, bytes, hipMemcpyHostToDevice), "copying previous frame");
+    for (int32_t done = 0; done < n_frames;) {
+        const int32_t k = n_frames - done < RT_MAX_BATCH_FRAMES ? n_frames - done : RT_MAX_BATCH_FRAMES;
+        rt_status st = rt_render_device_batch(ctx, scene, cam, rs, times_ms + done, k, *frame_num + done, nullptr, ctx->d_out, nullptr);
+        if (st != RT_OK) return st;
+        done += k;
+    }
+    RT_HIP(ctx, hipDeviceSynchronize(), "render kernel");
+    rt_status st = check_kernel_flag(ctx);
+    if (st != RT_OK) return st;
+    RT_HIP(ctx, hipMemcpy(previous_render, ctx->d_out, bytes, hipMemcpyDeviceToHost), "copying frame to host");
+    *frame_num += n_frames;
+    RT_HIP(ctx, hipPeekAtLastError(), "final check after render");
+    return RT_OK;
+}
+
 extern "C" rt_status rt_to_rgba8_device(rt_ctx *ctx, const float *d_rgb, int32_t width, int32_t height, uint8_t *d_rgba, void *hip_stream)
 {
     if (!ctx || !d_rgb || !d_rgba || width <= 0 || height <= 0) return set_err(ctx, RT_ERR_INVALID, "bad argument");

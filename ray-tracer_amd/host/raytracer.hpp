@@ -292,6 +292,17 @@ public:
         check(rt_render(ctx_, scene_, &cam.c, &rd.c, current_time_ms, &fn, data->previous_render.data()));
         data->frame_num = fn;
     }
+    /* several passes of the main loop body at once (src/main.cu:421-424, one seed per frame): the same
+     * image as that many render() calls, but the frames overlap on the GPU (rt_render_frames) */
+    void render_frames(const Camera &cam, const RenderData &rd, VariableRenderData *data, const std::vector<int> &times_ms)
+    {
+        if (data->previous_render.size() != (size_t)cam.c.width * (size_t)cam.c.height * 3) throw std::invalid_argument("previous_render has the wrong size");
+        if (times_ms.empty()) return;
+        std::vector<int32_t> t(times_ms.begin(), times_ms.end());
+        int32_t fn = data->frame_num;
+        check(rt_render_frames(ctx_, scene_, &cam.c, &rd.c, t.data(), (int32_t)t.size(), &fn, data->previous_render.data()));
+        data->frame_num = fn;
+    }
     float last_kernel_ms()
     {
         float ms = 0;

@@ -477,3 +477,21 @@ def test_multi_frame_launch_on_bands(rt, ctx):
         parts.append(buf)
     got = dm.assemble(torch.stack(parts), W, H, 8, world)
     assert torch.equal(got.contiguous().view(torch.int32), full.view(torch.int32))
+
+
+def test_render_frames_host_buffers(rt, ctx):
+    """rt_render_frames: 19 frames in one call (a 16-frame launch + a 3-frame launch) on top of two
+    frames rendered one by one == 21 render() calls"""
+    objs, sky = rt.scenes.cube()
+    scene = ctx.commit(rt.SceneObjects(objs))
+    W, H = 72, 40
+    cam, rd = rt.Camera(W, H), rt.RenderData(2, 4, True, sky)
+    a = rt.VariableRenderData(W, H)
+    for i in range(21):
+        rt.render(ctx, scene, cam, rd, a, 500 + i)
+    b = rt.VariableRenderData(W, H)
+    rt.render(ctx, scene, cam, rd, b, 500)
+    rt.render(ctx, scene, cam, rd, b, 501)
+    rt.render_frames(ctx, scene, cam, rd, b, [502 + i for i in range(19)])
+    assert a.frame_num == b.frame_num == 21
+    assert eq(a.previous_render, b.previous_render)
