@@ -3,7 +3,8 @@
 # repo root).  usage: tools/profile_all.sh <tag>
 #   pass 0: --kernel-trace --stats on the default bench.py command (no CPU-baseline leg)
 #   pass 1-3: SQ counters, pass 4/5: FETCH_SIZE / WRITE_SIZE, each in its own run (PMC and
-#   tracing are never combined), on one launch of the same workload (tools/profile_run.py).
+#   tracing are never combined), on one launch of the same workload (tools/profile_run.py: the
+#   3-frame launch of the default bench).
 set -o pipefail
 TAG=${1:-r01}
 export TMPDIR=/tmp
@@ -17,7 +18,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -- python3 tools/profile_run.py monkey 1024 > $OUT/pmc$i.log 2> $OUT/pmc$i.err
+  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -- python3 tools/profile_run.py monkey 1024 1920 1080 3 > $OUT/pmc$i.log 2> $OUT/pmc$i.err
   echo "pmc pass $i ($set) exit=$?"
 done
 python3 tools/summarize_profile.py $OUT > $OUT/summary.txt

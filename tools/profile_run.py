@@ -1,4 +1,5 @@
-"""One render of a config scene for rocprofv3 (development tool).  usage: profile_run.py [scene] [spp] [W] [H]"""
+"""One launch on a config scene for rocprofv3 (development tool): a plain frame, or `frames` progressive
+frames in one multi-frame launch.  usage: profile_run.py [scene] [spp] [W] [H] [frames]"""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,10 +9,15 @@ name = sys.argv[1] if len(sys.argv) > 1 else "monkey"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
 H = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
+frames = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 objs, sky = rt.scenes.CONFIG_SCENES[name]()
 ctx = rt.Context(0)
 scene = ctx.commit(rt.SceneObjects(objs))
 out = torch.empty((H, W, 3), device="cuda:0")
-rt.render_device(ctx, scene, rt.Camera(W, H), rt.RenderData(spp, 8, True, sky), 12345, 0, out.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+st = torch.cuda.current_stream().cuda_stream
+if frames > 1:
+    rt.render_device_batch(ctx, scene, rt.Camera(W, H), rt.RenderData(spp, 8, True, sky), [12345 + i for i in range(frames)], 0, out.data_ptr(), stream=st)
+else:
+    rt.render_device(ctx, scene, rt.Camera(W, H), rt.RenderData(spp, 8, True, sky), 12345, 0, out.data_ptr(), stream=st)
 ms = ctx.last_kernel_ms()
-print("%s %dx%d spp=%d: %.2f ms, %.1f Msamples/s" % (name, W, H, spp, ms, W * H * spp / ms / 1e3))
+print("%s %dx%d spp=%d x %d frame(s) in one launch: %.2f ms, %.1f Msamples/s" % (name, W, H, spp, frames, ms, W * H * spp * frames / ms / 1e3))

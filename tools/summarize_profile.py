@@ -21,7 +21,7 @@ for f in sorted(glob.glob(os.path.join(d, "pmc*", "*", "*_counter_collection.csv
         if "rt_render_kernel" in row["Kernel_Name"]:
             t[row["Counter_Name"]] += float(row["Counter_Value"])
             n[row["Counter_Name"]] += 1
-print("\n## PMC counters, one launch of rt_render_kernel (monkey 1920x1080, 1024 spp, 8 bounces), summed over the device")
+print("\n## PMC counters, one launch of rt_render_kernel (monkey 1920x1080, 1024 spp, 8 bounces, 3 progressive frames in the launch), summed over the device")
 for k in sorted(t):
     print("%-26s %.6g" % (k, t[k]))
 if t.get("SQ_ACTIVE_INST_VALU"):
