@@ -20,6 +20,7 @@
 /* 16-byte vector for LDS / global accesses: a single ds_read_b128 / global_load_dwordx4 each
  * (a struct of four floats gets split into narrower loads by the optimiser) */
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v3f __attribute__((ext_vector_type(3)));
 
 struct V3 { float x, y, z; };
 
@@ -215,17 +216,17 @@ __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, 
         V3 previous = v3(0.f, 0.f, 0.f);
         if (p.frame > 0) {
             if (__hip_atomic_load(a.pixel_done + pixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint32_t)p.frame) { p.mode = M_BLEND; return; }
-            previous.x = __hip_atomic_load(dst + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            previous.y = __hip_atomic_load(dst + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            previous.z = __hip_atomic_load(dst + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            /* the three floats in ONE agent-scope access (an sc1 dword is a fabric transaction of its own) */
+            v3f pv;
+            asm volatile("global_load_dwordx3 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(pv) : "v"(dst) : "memory");
+            previous = v3(pv.x, pv.y, pv.z);
         } else if (n > 0) {
             previous = v3(dst[0], dst[1], dst[2]);                 /* what the caller put there before the launch */
         }
         const V3 res = (c + previous * (float)n) / (float)(n + 1);
-        __hip_atomic_store(dst + 0, res.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, res.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 2, res.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        v3f rv;
+        rv.x = res.x; rv.y = res.y; rv.z = res.z;
+        asm volatile("global_store_dwordx3 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : : "v"(dst), "v"(rv) : "memory");
         __hip_atomic_store(a.pixel_done + pixel, (uint32_t)(p.frame + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         p.mode = M_FETCH;
         return;
