@@ -20,13 +20,22 @@
  *    traversing; lanes whose ray missed every mesh box, or finished early, go on shading and
  *    generating instead of idling behind the longest traversal;
  *  - the whole scene (BVH nodes with child boxes inline, 48-byte triangles, per-object
- *    shading record) is staged into LDS once per workgroup; the object list itself is read
- *    with scalar loads because every lane walks it in the same order;
+ *    shading record, the object list) is staged into LDS once per workgroup; the object list is
+ *    read with wave-uniform addresses (one broadcast per quad) because every lane walks it in
+ *    the same order;
  *  - BVH traversal keeps the current node in a register and only the deferred sibling (with
  *    its entry distance) on a per-lane LDS stack laid out [entry][thread], which is
  *    bank-conflict-free; a box is tested once, not twice as in the reference, by carrying the
  *    entry distance instead of re-testing on pop (same predicate, same outcome);
- *  - RNG state, ray, throughput and accumulators live in registers.
+ *  - RNG state, ray, throughput and accumulators live in registers;
+ *  - one launch can render several consecutive progressive frames (rt_render_device_batch): the
+ *    tickets of frame k + 1 follow those of frame k, so free waves start the next frame while the
+ *    last expensive tiles of a frame finish; a pixel's frames are blended in order through a
+ *    per-pixel counter (rt_pixel.h, px_finish_pixel).
+ *
+ * The per-pixel sections (shade / fetch / generate, the primitive tests) are in rt_pixel.h; this
+ * file has the two kernels built from them - rt_render_kernel (the default) and the opt-in
+ * rt_render_pool_kernel - and the launchers.
  *
  * No MFMA: there is no dense contraction anywhere in this workload.
  * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the reference's a*b+c are two
