@@ -9,6 +9,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +42,11 @@ struct rt_ctx {
     size_t done_cap = 0;
     size_t tile_order_cap = 0;
     std::vector<uint32_t> order_key;     /* what the cached order was built for */
+    std::vector<uint32_t> order_host;    /* that order (host copy) */
+    uint32_t *d_tile_cost = nullptr;     /* per tile: traversal macro steps of its pixels, collected by the first launch of a view */
+    int cost_state = 0;                  /* 0 nothing, 1 the last launch with this key collected costs, 2 the order has been refined with them */
+    int order_num_heavy = 0;             /* refined order: how many leading tiles go first for ALL frames of a multi-frame launch */
+    int heavy_top = 1024;                /* RT_AMD_HEAVY_TOP: that many at most (0 = never refine) */
     int heavy_first = 1;                 /* RT_AMD_HEAVY_FIRST=0 disables */
     int work_threshold = 8;      /* lanes; RT_AMD_WORK_THRESHOLD overrides (tuning: tools/ab_threshold.py) */
     int descend_keep = 24;       /* RT_AMD_DESCEND_KEEP (0..64): 0 = run every descent to its end */
@@ -121,6 +127,7 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (const char *e = getenv("RT_AMD_DESCEND_KEEP")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->descend_keep = v; }
     if (const char *e = getenv("RT_AMD_TILE_SCATTER")) ctx->tile_scatter = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_HEAVY_FIRST")) ctx->heavy_first = atoi(e) != 0;
+    if (const char *e = getenv("RT_AMD_HEAVY_TOP")) { int v = atoi(e); if (v >= 0) ctx->heavy_top = v; }
     if (const char *e = getenv("RT_AMD_HIT_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->hit_break = v; }
     if (const char *e = getenv("RT_AMD_SHADE_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->shade_batch = v; }
     if (const char *e = getenv("RT_AMD_POOL")) ctx->use_pool = atoi(e) != 0;
@@ -145,6 +152,7 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     if (ctx->d_prev) (void)hipFree(ctx->d_prev);
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
+    if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -358,15 +366,49 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
                 }
                 if (ctx->tile_order_cap < n) {
                     if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
-                    ctx->d_tile_order = nullptr;
+                    if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
+                    ctx->d_tile_order = ctx->d_tile_cost = nullptr;
                     ctx->tile_order_cap = 0;
                     RT_HIP(ctx, hipMalloc((void **)&ctx->d_tile_order, (size_t)n * 4), "allocating tile order");
+                    RT_HIP(ctx, hipMalloc((void **)&ctx->d_tile_cost, (size_t)n * 4), "allocating tile costs");
                     ctx->tile_order_cap = n;
                 }
                 RT_HIP(ctx, hipMemcpyAsync(ctx->d_tile_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream), "uploading tile order");
                 RT_HIP(ctx, hipStreamSynchronize(stream), "uploading tile order");     /* `order` is a local */
                 ctx->order_key = key;
+                ctx->order_host.swap(order);
+                ctx->order_num_heavy = 0;
+                ctx->cost_state = 0;
             }
+            /* The guess above is refined once per view with what the tiles really cost: the first
+             * launch of a view also adds up, per tile, the traversal steps of its pixels; the second
+             * reads them back (one synchronisation) and moves the `heavy_top` most expensive tiles to
+             * the front, most expensive first within rounds of one ticket per wave.  In a multi-frame
+             * launch those tiles go first for ALL frames (see px_fetch): with the true costs that is
+             * worth 10 % at three frames per launch (with the guess, nothing). */
+            if (ctx->cost_state == 0 && ctx->heavy_top > 0) {
+                RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)n * 4, stream), "clearing tile costs");
+                a.tile_cost = ctx->d_tile_cost;
+                ctx->cost_state = 1;
+            } else if (ctx->cost_state == 1) {
+                std::vector<uint32_t> cost(n);
+                RT_HIP(ctx, hipMemcpy(cost.data(), ctx->d_tile_cost, (size_t)n * 4, hipMemcpyDeviceToHost), "reading tile costs");
+                std::vector<uint32_t> idx(ctx->order_host);
+                std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+                uint32_t top = (uint32_t)ctx->heavy_top < n ? (uint32_t)ctx->heavy_top : n;
+                while (top > 0 && cost[idx[top - 1]] == 0) top--;
+                std::vector<char> taken(n, 0);
+                std::vector<uint32_t> merged;
+                merged.reserve(n);
+                const uint32_t st = ctx->tile_scatter ? coprime_stride(top) : 1u;
+                for (uint32_t i = 0; i < top; i++) { const uint32_t t = idx[(size_t)(((uint64_t)i * st) % top)]; merged.push_back(t); taken[t] = 1; }
+                for (uint32_t t : ctx->order_host) if (!taken[t]) merged.push_back(t);
+                RT_HIP(ctx, hipMemcpy(ctx->d_tile_order, merged.data(), (size_t)n * 4, hipMemcpyHostToDevice), "uploading tile order");
+                ctx->order_host.swap(merged);
+                ctx->order_num_heavy = (int)top;
+                ctx->cost_state = 2;
+            }
+            a.num_heavy_tiles = (ctx->cost_state == 2 && n_frames > 1) ? ctx->order_num_heavy : 0;
             a.tile_order = ctx->d_tile_order;
         }
     }

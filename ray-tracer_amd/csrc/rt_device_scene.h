@@ -105,6 +105,7 @@ typedef struct {
     int32_t num_tiles;             /* tiles this launch renders */
     uint32_t tile_stride;          /* ticket t renders tile (t * tile_stride) % num_tiles; coprime to num_tiles */
     const uint32_t *tile_order;    /* or, if not NULL, tile tile_order[t] (expensive-looking tiles first) */
+    int32_t num_heavy_tiles;       /* multi-frame launches: this many leading entries of tile_order go first for ALL frames */
     /* scene */
     const rt_object *objects;
     int32_t num_objects;
@@ -128,6 +129,7 @@ typedef struct {
     const float *prev;             /* full frame or NULL */
     float *out;
     uint32_t *tile_counter;        /* zeroed before the launch */
+    uint32_t *tile_cost;           /* or NULL: per tile, the traversal macro steps its pixels took (all frames of the launch) */
     unsigned long long *stats;     /* development builds only (-DRT_STATS): section counters */
 } rt_kernel_args;
 

@@ -140,7 +140,9 @@ struct Px {
     float cur_n;                 /* Ray::current_refractive_index src/ray.cu:56,144 */
     float best_t;
     int best_obj, best_prim, next_mesh;
-    int frame;                   /* which frame of a multi-frame launch this pixel belongs to */
+    /* bits 3..0: which frame of a multi-frame launch this pixel belongs to; bits 31..4: the traversal
+     * macro steps it has cost so far, reported per tile when the launch collects costs (tile_cost) */
+    unsigned frame_steps;
 #ifdef RT_COSTMAP
     /* development build (tools/costmap.py): the frame holds, per pixel, (own traversal steps,
      * start tick, end tick) of the 100 MHz wall clock instead of the colour */
@@ -173,7 +175,7 @@ __device__ __forceinline__ void px_init(Px &p)
     p.colour = z; p.fin = z; p.thr = z; p.o = z; p.d = z; p.inv = z; p.primary = z;
     p.sample = 0; p.bounce = 0; p.px = 0; p.py = 0;
     p.cur_n = 1.0f; p.best_t = RT_INF_F;
-    p.best_obj = -1; p.best_prim = -1; p.next_mesh = 0; p.frame = 0;
+    p.best_obj = -1; p.best_prim = -1; p.next_mesh = 0; p.frame_steps = 0;
     RT_COST(p.c_steps = 0; p.c_t0 = 0; p.c_wsteps = 0);
 }
 
@@ -211,11 +213,18 @@ __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, 
     }
     const size_t pixel = (size_t)out_row * (size_t)f.W + (size_t)p.px;
     float *dst = a.out + pixel * 3;
+    const int frame = (int)(p.frame_steps & 15u);
+    if (a.tile_cost && (a.pixel_done == nullptr || frame == 0 || __hip_atomic_load(a.pixel_done + pixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)frame)) {
+        /* (first launch of a view) what this pixel cost, charged to its tile; not when the lane is about to park */
+        const int band = p.py / a.band_rows;
+        const int tile = ((band - a.band_first) / a.band_stride) * f.tiles_per_band + ((p.py - band * a.band_rows) >> 3) * a.tiles_x + (p.px >> 3);
+        atomicAdd(a.tile_cost + tile, p.frame_steps >> 4);
+    }
     if (a.pixel_done) {
-        const int n = a.frame_num + p.frame;
+        const int n = a.frame_num + frame;
         V3 previous = v3(0.f, 0.f, 0.f);
-        if (p.frame > 0) {
-            if (__hip_atomic_load(a.pixel_done + pixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint32_t)p.frame) { p.mode = M_BLEND; return; }
+        if (frame > 0) {
+            if (__hip_atomic_load(a.pixel_done + pixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint32_t)frame) { p.mode = M_BLEND; return; }
             /* the three floats in ONE agent-scope access (an sc1 dword is a fabric transaction of its own) */
             v3f pv;
             asm volatile("global_load_dwordx3 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(pv) : "v"(dst) : "memory");
@@ -227,7 +236,7 @@ __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, 
         v3f rv;
         rv.x = res.x; rv.y = res.y; rv.z = res.z;
         asm volatile("global_store_dwordx3 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : : "v"(dst), "v"(rv) : "memory");
-        __hip_atomic_store(a.pixel_done + pixel, (uint32_t)(p.frame + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.pixel_done + pixel, (uint32_t)(frame + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         p.mode = M_FETCH;
         return;
     }
@@ -404,10 +413,24 @@ __device__ __forceinline__ void px_fetch(Px &p, Chunk &ch, const rt_kernel_args 
         uint32_t t = 0;
         if (lane == 0) t = atomicAdd(a.tile_counter, 1u);
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        /* tickets run frame by frame (a single-frame launch has num_frames == 1) */
-        const uint32_t fr = t / (uint32_t)a.num_tiles;
-        if (fr >= (uint32_t)a.num_frames) { ch.exhausted = true; break; }
-        t -= fr * (uint32_t)a.num_tiles;
+        /* Tickets of a multi-frame launch: first the `num_heavy_tiles` most expensive tiles (the
+         * head of tile_order) of frame 0, of frame 1, ... of the last frame, then the other tiles
+         * frame by frame.  Frames only meet in the blend of a pixel, so the longest jobs of EVERY
+         * frame can start at once and everything else fills in behind them: the launch is then as
+         * long as its work, not as its last frame's tail.  (num_heavy_tiles == 0, or one frame:
+         * plainly frame by frame.) */
+        if (t >= (uint32_t)a.num_tiles * (uint32_t)a.num_frames) { ch.exhausted = true; break; }
+        uint32_t fr;
+        const uint32_t nh = (uint32_t)a.num_heavy_tiles;
+        if (t < nh * (uint32_t)a.num_frames) {
+            fr = t / nh;
+            t -= fr * nh;
+        } else {
+            const uint32_t nl = (uint32_t)a.num_tiles - nh;
+            t -= nh * (uint32_t)a.num_frames;
+            fr = t / nl;
+            t = nh + (t - fr * nl);
+        }
         ch.frame = (int)fr;
         /* ticket -> tile through a permutation.  A pixel's samples are sequential, so the frame
          * cannot finish before its most expensive tile does; the host therefore lists the tiles
@@ -432,7 +455,7 @@ __device__ __forceinline__ void px_fetch(Px &p, Chunk &ch, const rt_kernel_args 
         /* src/raytracer.cu:123-127; Ray::set_direction_origin src/ray.cu:147-155,
          * cam_pixel_to_world src/camera.cu:24-29 */
         const int array_index = (p.py * f.W + p.px) * 3;
-        p.frame = my_frame;
+        p.frame_steps = (unsigned)my_frame;
         p.rng = (uint32_t)array_index * 3145739u + a.seeds[my_frame];
         RT_COST(p.c_steps = 0; p.c_wsteps = 0; p.c_t0 = (unsigned)wall_clock64());
         V3 plane_point = f.du * (float)p.px + f.dv * (float)p.py;
