@@ -17,8 +17,14 @@ if os.path.exists(bj):
 t = collections.defaultdict(float)
 n = collections.defaultdict(int)
 for f in sorted(glob.glob(os.path.join(d, "pmc*", "*", "*_counter_collection.csv"))):
-    for row in csv.DictReader(open(f)):
-        if "rt_render_kernel" in row["Kernel_Name"]:
+    rows = [row for row in csv.DictReader(open(f)) if "rt_render_kernel" in row["Kernel_Name"]]
+    if not rows:
+        continue
+    # tools/profile_run.py launches a 1-spp warm-up first (the first launch of a view also measures tile
+    # costs); the profiled launch is the last dispatch of the kernel
+    last = max(int(row["Dispatch_Id"]) for row in rows)
+    for row in rows:
+        if int(row["Dispatch_Id"]) == last:
             t[row["Counter_Name"]] += float(row["Counter_Value"])
             n[row["Counter_Name"]] += 1
 print("\n## PMC counters, one launch of rt_render_kernel (monkey 1920x1080, 1024 spp, 8 bounces, 3 progressive frames in the launch), summed over the device")
