@@ -492,7 +492,6 @@ extern "C" rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, 
 {
     if (!times_ms || n_frames < 1 || n_frames > RT_MAX_BATCH_FRAMES) return set_err(ctx, RT_ERR_INVALID, "n_frames must be 1..16");
     if (frame_num < 0) return set_err(ctx, RT_ERR_INVALID, "bad frame number");
-    if (scene && scene->pool) return set_err(ctx, RT_ERR_UNSUPPORTED, "multi-frame launches are not available with RT_AMD_POOL=1");
     return render_frames(ctx, scene, cam, rs, times_ms, n_frames, frame_num, tiles, nullptr, d_frame, hip_stream, true);
 }
 

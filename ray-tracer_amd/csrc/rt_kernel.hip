@@ -473,6 +473,8 @@ __global__ __launch_bounds__(NT) void rt_render_pool_kernel(const rt_kernel_args
             }
             p.mode = p.next_mesh >= a.num_meshes ? M_SHADE : M_MESH;
         }
+        /* (multi-frame launches) a finished pixel whose previous frame was not stored yet: try again */
+        if (p.mode == M_BLEND) px_finish_pixel(p, a, f);
         const int n_live = __popcll(__ballot(p.mode != M_DONE));
         int n_ready = __popcll(__ballot(p.mode == M_SHADE || p.mode == M_MESH || p.mode == M_GEN || p.mode == M_FETCH));
         const int half_live = (n_live + 1) >> 1;
