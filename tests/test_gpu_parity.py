@@ -312,19 +312,24 @@ def test_textured_and_refractive_primitives(rt, orc, ctx, models_dir):
     assert np.isfinite(got).all()
 
 
-def test_scene_larger_than_lds_uses_global_memory(rt, orc, ctx, models_dir):
-    """maximum sizes: a 6,000-triangle mesh (BVH + triangles ~ 350 KB) cannot be staged into a
-    CU's 160 KB LDS; the kernel then reads the scene from global memory and must still match"""
+def _big_mesh_scene(rt, n=6000):
+    """a mesh of n random small triangles over a checkerboard ground: too large for a CU's LDS"""
     rng = np.random.default_rng(9)
-    n = 6000
     centres = rng.uniform([-1.2, -0.6, 1.2], [1.2, 0.8, 3.5], (n, 3))
     tris = (centres[:, None, :] + rng.normal(0, 0.05, (n, 3, 3))).astype(np.float32).reshape(n, 9)
     objs = [("mesh", tris, ("standard", (0.8, 0.7, 0.6), 0.1)),
             ("sphere", (0, -100.5, 1.5), 100, ("checkerboard", (0.9, 0.9, 0.9), (0.3, 0.3, 0.3), 4000, 0))]
+    return objs, (0.8, 1.0, 1.0)
+
+
+def test_scene_larger_than_lds_uses_global_memory(rt, orc, ctx, models_dir):
+    """maximum sizes: a 6,000-triangle mesh (BVH + triangles ~ 350 KB) cannot be staged into a
+    CU's 160 KB LDS; the kernel then reads the scene from global memory and must still match"""
+    n = 6000
+    objs, sky = _big_mesh_scene(rt, n)
     scene = ctx.commit(rt.SceneObjects(objs))
     info = scene.info()
     assert info["scene_in_lds"] == 0 and info["num_triangles"] == n
-    sky = (0.8, 1.0, 1.0)
     got = hip_render(rt, ctx, objs, 160, 96, 4, 6, sky)
     want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(160, 96).floats(), 160, 96, 4, 6, sky)
     assert eq(got, want)
@@ -422,7 +427,10 @@ def test_tiny_and_thin_images(rt, orc, ctx, models_dir, name):
 
 
 @pytest.mark.parametrize("name,W,H,spp,limit,frames", [("monkey", 200, 120, 6, 8, 4), ("three_sphere", 160, 96, 4, 8, 5),
-                                                       ("reference_scene0", 125, 100, 3, 5, 3), ("cube", 96, 64, 5, 8, 16)])
+                                                       ("reference_scene0", 125, 100, 3, 5, 3), ("cube", 96, 64, 5, 8, 16),
+                                                       ("reference_scene2", 100, 80, 3, 5, 4),      # image texture
+                                                       ("reference_scene3", 96, 72, 3, 8, 4),       # refraction (a draw inside shading)
+                                                       ("reference_scene4", 120, 68, 2, 6, 4)])     # 100 spheres, no mesh
 def test_multi_frame_launch_equals_frame_by_frame(rt, orc, ctx, models_dir, name, W, H, spp, limit, frames):
     """rt_render_device_batch: F progressive frames in ONE launch (frame k+1 is traced while frame k's
     expensive pixels still run; the blend of a pixel waits for its previous frame) must give the image
@@ -495,3 +503,23 @@ def test_render_frames_host_buffers(rt, ctx):
     rt.render_frames(ctx, scene, cam, rd, b, [502 + i for i in range(19)])
     assert a.frame_num == b.frame_num == 21
     assert eq(a.previous_render, b.previous_render)
+
+
+def test_multi_frame_launch_full_size_and_global_scene(rt, ctx):
+    """the multi-frame launch where every CU takes part (1920x1080: hand-overs between XCDs), and on a
+    scene that is read from global memory (LDS holds only the stacks): frames in one launch == frame
+    by frame"""
+    import torch
+    st = torch.cuda.current_stream().cuda_stream
+    for objs, sky, W, H, spp, frames in ((*rt.scenes.monkey(), 1920, 1080, 2, 5), (*_big_mesh_scene(rt), 320, 200, 2, 3)):
+        scene = ctx.commit(rt.SceneObjects(objs))
+        cam, rd = rt.Camera(W, H), rt.RenderData(spp, 8, True, sky)
+        times = [900 + i for i in range(frames)]
+        a = torch.zeros((H, W, 3), device="cuda:0"); b = torch.empty_like(a)
+        for i, t in enumerate(times):
+            rt.render_device(ctx, scene, cam, rd, t, i, b.data_ptr(), d_prev=a.data_ptr() if i else None, stream=st)
+            a, b = b, a
+        fr = torch.empty((H, W, 3), device="cuda:0")
+        for _ in range(2):          # twice: the second launch of the view runs with the refined tile order
+            rt.render_device_batch(ctx, scene, cam, rd, times, 0, fr.data_ptr(), stream=st)
+            assert torch.equal(fr.view(torch.int32), a.view(torch.int32))
