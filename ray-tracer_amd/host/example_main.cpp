@@ -4,7 +4,7 @@
  * progressive frames, write the float->RGBA8 result (src/main.cu:343-371) as a binary PPM or,
  * if the name ends in .png, as a PNG like the reference's images/ directory.
  *
- *   example_main <models_dir> <scene 0|1> <width> <height> <frames> <out.ppm|out.png>
+ *   example_main <models_dir> <scene 0..3> <width> <height> <frames> <out.ppm|out.png>
  *
  * Build:  g++ -std=c++17 -O2 example_main.cpp -L.. -lraytracer_amd -Wl,-rpath,'$ORIGIN/..'
  */
@@ -20,7 +20,7 @@ using namespace rtamd;
 int main(int argc, char **argv)
 {
     if (argc < 7) {
-        std::fprintf(stderr, "usage: %s <models_dir> <scene 0|1> <width> <height> <frames> <out.ppm|out.png>\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <models_dir> <scene 0..3> <width> <height> <frames> <out.ppm|out.png>\n", argv[0]);
         return 2;
     }
     const std::string models = argv[1];

@@ -238,9 +238,14 @@ def test_cpp_host_mirror_end_to_end(rt, orc, models_dir, tmp_path):
     bmod = __import__("importlib").import_module("ray-tracer_amd.build")
     exe = bmod.build_example()
     W, H, frames = 80, 64, 2
-    for scene_num, name in ((1, "reference_scene1"), (0, "reference_scene0")):
+    # scene 2 reads textures/parsed_textures.txt (relative, like the reference): bake a procedural image there
+    img = rt.scenes.procedural_image(24, 12, seed=3)
+    (tmp_path / "textures").mkdir()
+    with open(tmp_path / "textures" / "parsed_textures.txt", "w") as fh:
+        fh.write("earth.png\n24\n12\n" + "".join("%s %s %s " % tuple(repr(float(c)) for c in px) for row in img for px in row) + "\n")
+    for scene_num, name in ((1, "reference_scene1"), (0, "reference_scene0"), (2, "reference_scene2"), (3, "reference_scene3")):
         out = tmp_path / ("s%d.%s" % (scene_num, "png" if scene_num == 1 else "ppm"))
-        subprocess.check_call([exe, models_dir, str(scene_num), str(W), str(H), str(frames), str(out)], timeout=300)
+        subprocess.check_call([exe, models_dir, str(scene_num), str(W), str(H), str(frames), str(out)], timeout=300, cwd=str(tmp_path))
         if scene_num == 1:
             from test_png import decode_png
             got = decode_png(out)
@@ -249,7 +254,7 @@ def test_cpp_host_mirror_end_to_end(rt, orc, models_dir, tmp_path):
             header = ("P6\n%d %d\n255\n" % (W, H)).encode()
             assert raw.startswith(header)
             got = np.frombuffer(raw[len(header):], np.uint8).reshape(H, W, 3)
-        objs, sky = rt.scenes.CONFIG_SCENES[name]()
+        objs, sky = rt.scenes.reference_scene2(img) if scene_num == 2 else rt.scenes.CONFIG_SCENES[name]()
         o = orc.Scene(objs, orc.MATH_DET, models_dir)
         prev = None
         for f in range(frames):
