@@ -528,3 +528,23 @@ def test_multi_frame_launch_full_size_and_global_scene(rt, ctx):
         for _ in range(2):          # twice: the second launch of the view runs with the refined tile order
             rt.render_device_batch(ctx, scene, cam, rd, times, 0, fr.data_ptr(), stream=st)
             assert torch.equal(fr.view(torch.int32), a.view(torch.int32))
+
+
+def test_batch_entry_one_frame_at_a_time(rt, ctx):
+    """rt_render_device_batch with ONE frame per call, accumulating in place over several calls, is the
+    frame-by-frame loop with a single buffer"""
+    import torch
+    objs, sky = rt.scenes.three_sphere()
+    scene = ctx.commit(rt.SceneObjects(objs))
+    W, H = 90, 50
+    cam, rd = rt.Camera(W, H), rt.RenderData(3, 6, True, sky)
+    st = torch.cuda.current_stream().cuda_stream
+    a = torch.zeros((H, W, 3), device="cuda:0"); b = torch.empty_like(a)
+    fr = torch.empty((H, W, 3), device="cuda:0")
+    for i in range(4):
+        rt.render_device(ctx, scene, cam, rd, 70 + i, i, b.data_ptr(), d_prev=a.data_ptr() if i else None, stream=st)
+        a, b = b, a
+        rt.render_device_batch(ctx, scene, cam, rd, [70 + i], i, fr.data_ptr(), stream=st)
+        assert torch.equal(fr.view(torch.int32), a.view(torch.int32)), i
+    with pytest.raises(ValueError, match="1..16"):
+        rt.render_device_batch(ctx, scene, cam, rd, list(range(17)), 0, fr.data_ptr(), stream=st)     # more than 16 frames per launch
