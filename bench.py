@@ -102,6 +102,7 @@ def main():
                     help="N > 1: weak = image area grows with N (default), strong = the same WxH frame for every N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frame-by-frame", action="store_true", help="one launch + one gather per step instead of one multi-frame launch for all steps")
+    ap.add_argument("--no-frame-by-frame-leg", action="store_true", help="skip the extra one-launch-per-step measurement (keeps a profile's launches all of one kind)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-gpu rehearses N ranks on ONE GPU (RCCL refuses duplicate devices)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
@@ -198,7 +199,7 @@ def main():
     batched = not args.frame_by_frame
     elapsed, frame, kernel_ms, frames_per_launch, cam = measure(W, H, args.warmup, args.steps, batched)
     per_frame = None
-    if batched and rank == 0 and world == 1:
+    if batched and rank == 0 and world == 1 and not args.no_frame_by_frame_leg:
         # for the record: the same number of steps with one launch per frame (what `value` was before
         # multi-frame launches existed); not the headline value
         f_elapsed, _, _, _, _ = measure(W, H, 0, args.steps, False)

@@ -3,7 +3,7 @@ import collections, csv, glob, json, os, sys
 d = sys.argv[1]
 print("# rocprofv3 summary of", d)
 for f in glob.glob(os.path.join(d, "stats", "*", "*_kernel_stats.csv")):
-    print("\n## kernel stats (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline)")
+    print("\n## kernel stats (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-frame-by-frame-leg)")
     for i, row in enumerate(csv.reader(open(f))):
         if i < 6:
             print(",".join(row))
