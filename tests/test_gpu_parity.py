@@ -418,6 +418,14 @@ def test_pooled_kernel_equals_oracle(rt, orc, models_dir, monkeypatch, name, W, 
     # several frames in a row through the same context (queues and flags start clean every launch)
     again = hip_render(rt, pctx, objs, W, H, spp, limit, sky)
     assert eq(again, want)
+    # ... and a multi-frame launch through the pooled kernel
+    data = rt.VariableRenderData(W, H)
+    rt.render_frames(pctx, scene, rt.Camera(W, H), rt.RenderData(spp, limit, True, sky), data, [12345, 12346, 12347])
+    o = orc.Scene(objs, orc.MATH_DET, models_dir)
+    prev = want
+    for i in (1, 2):
+        prev = o.render(rt.Camera(W, H).floats(), W, H, spp, limit, sky, time_ms=12345 + i, frame_num=i, prev=prev)
+    assert eq(data.previous_render, prev)
 
 
 @pytest.mark.parametrize("name", ["monkey", "three_sphere"])
