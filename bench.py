@@ -237,8 +237,7 @@ def main():
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms_avg": avg_kernel_s * 1e3, "frames_per_launch": avg_frames,
                 "note": "24 B/pixel/frame + scene once; the path is VALU/latency-bound, see 'valu'"
-                        + ("; 'traffic' of a multi-frame launch is dominated by the per-pixel hand-over between frames: agent-scope write-through "
-                           "accesses of 4-12 bytes that the fabric moves as 32/64-byte transactions (DESIGN.md section 4), ~1.4 GB/s" if batched else "")}
+                        + ("; a multi-frame launch writes one plane of per-pixel means per frame, folded into the frame by a small kernel behind it" if batched else "")}
 
     out = {"metric": "Msamples/sec (WxHxspp) at %dx%d, %d bounces" % (args.width, args.height, limit), "value": value, "unit": "Msamples/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

@@ -189,9 +189,11 @@ rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *
  * seeded with times_ms[0..n_frames) - accumulated IN PLACE in d_frame (same layout as d_out above; when
  * frame_num > 0 its content is the image after frame_num - 1, otherwise it is ignored).  The result is
  * bit-identical to n_frames rt_render_device calls.  Every frame has its own random stream, so frame
- * k + 1 of a pixel is traced while the expensive pixels of frame k are still running; only the final
- * blend of a pixel waits for its previous frame (a per-pixel counter in HBM).  A launch per frame leaves
- * most of the GPU idle while the few most expensive tiles finish. */
+ * k + 1 of a pixel is traced while the expensive pixels of frame k are still running; each frame stores
+ * its per-pixel mean into a scratch plane and a small kernel behind the render kernel folds the planes
+ * into d_frame in frame order ((c + prev * n) / (n + 1), src/raytracer.cu:109-112).  A launch per frame
+ * leaves most of the GPU idle while the few most expensive tiles finish.  The context
+ * keeps n_frames planes of the frame's size in HBM. */
 rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
                                  const int32_t *times_ms, int32_t n_frames, int32_t frame_num, const rt_tile_spec *tiles,
                                  float *d_frame, void *hip_stream);

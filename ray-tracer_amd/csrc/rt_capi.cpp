@@ -21,6 +21,7 @@
 
 extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t rt_launch_render_pool(const rt_kernel_args *args, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t rt_launch_blend(const float *partial, long long plane_floats, int num_frames, int frame_num, float *frame, long long n_floats, hipStream_t stream);
 extern "C" hipError_t rt_launch_eval(int op, const uint32_t *in, uint32_t *out, int n, hipStream_t stream);
 extern "C" hipError_t rt_launch_rgba8(const float *rgb, int n_pixels, uint8_t *out, hipStream_t stream);
 
@@ -38,8 +39,8 @@ struct rt_ctx {
     size_t frame_bytes = 0;
     /* cached tile order (longest-job-first heuristic) for the last (scene, camera, tile spec) */
     uint32_t *d_tile_order = nullptr;
-    uint32_t *d_done = nullptr;          /* multi-frame launches: frames stored per pixel */
-    size_t done_cap = 0;
+    float *d_partial = nullptr;          /* multi-frame launches: one plane of per-pixel frame means per frame */
+    size_t partial_cap = 0;              /* floats */
     size_t tile_order_cap = 0;
     std::vector<uint32_t> order_key;     /* what the cached order was built for */
     std::vector<uint32_t> order_host;    /* that order (host copy) */
@@ -153,7 +154,7 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
     if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
-    if (ctx->d_done) (void)hipFree(ctx->d_done);
+    if (ctx->d_partial) (void)hipFree(ctx->d_partial);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;
@@ -438,17 +439,19 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
     a.tile_counter = ctx->tile_counter;
     a.stats = (unsigned long long *)(ctx->tile_counter + 16);   /* 48 x u64 after the counter; used by -DRT_STATS builds only */
 
+    size_t plane_floats = 0;
     if (in_place) {
-        const size_t px_count = (size_t)(a.compact ? owned_rows : cam->height) * (size_t)cam->width;
-        if (ctx->done_cap < px_count) {
-            if (ctx->d_done) (void)hipFree(ctx->d_done);
-            ctx->d_done = nullptr;
-            ctx->done_cap = 0;
-            RT_HIP(ctx, hipMalloc((void **)&ctx->d_done, px_count * 4), "allocating per-pixel frame counters");
-            ctx->done_cap = px_count;
+        plane_floats = (size_t)(a.compact ? owned_rows : cam->height) * (size_t)cam->width * 3;
+        const size_t need = plane_floats * (size_t)n_frames;
+        if (ctx->partial_cap < need) {
+            if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+            ctx->d_partial = nullptr;
+            ctx->partial_cap = 0;
+            RT_HIP(ctx, hipMalloc((void **)&ctx->d_partial, need * 4), "allocating the per-frame planes of a multi-frame launch");
+            ctx->partial_cap = need;
         }
-        RT_HIP(ctx, hipMemsetAsync(ctx->d_done, 0, px_count * 4, stream), "clearing per-pixel frame counters");
-        a.pixel_done = ctx->d_done;
+        a.partial = ctx->d_partial;
+        a.partial_plane = (int64_t)(plane_floats / 3);
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_start, stream), "recording start event");
     ctx->have_timing = false;
@@ -468,6 +471,20 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
             RT_HIP(ctx, rt_launch_render_pool(&a, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
         else
             RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
+    }
+    if (in_place && a.num_tiles > 0) {
+        /* the pixels this launch owns: full layout = its bands inside the frame (other rows stay as they
+         * are only in the compact layout, where the buffer holds nothing else), so fold band by band */
+        if (a.compact || a.band_stride == 1) {
+            RT_HIP(ctx, rt_launch_blend(ctx->d_partial, (long long)plane_floats, n_frames, frame_num, d_out, (long long)plane_floats, stream), "launching blend kernel");
+        } else {
+            const int bands_total = (cam->height + a.band_rows - 1) / a.band_rows;
+            for (int b = a.band_first; b < bands_total; b += a.band_stride) {
+                const int row0 = b * a.band_rows, row1 = row0 + a.band_rows < cam->height ? row0 + a.band_rows : cam->height;
+                const long long off = (long long)row0 * cam->width * 3, cnt = (long long)(row1 - row0) * cam->width * 3;
+                RT_HIP(ctx, rt_launch_blend(ctx->d_partial + off, (long long)plane_floats, n_frames, frame_num, d_out + off, cnt, stream), "launching blend kernel");
+            }
+        }
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream), "recording stop event");
     ctx->have_timing = true;

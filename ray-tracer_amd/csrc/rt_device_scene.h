@@ -97,8 +97,10 @@ typedef struct {
     uint32_t seeds[RT_MAX_BATCH_FRAMES];   /* per frame of the launch: (uint32)time_ms * 6291469  (src/raytracer.cu:127) */
     int32_t num_frames;            /* progressive frames rendered by this launch (1: a plain frame) */
     int32_t frame_num;             /* frame_num of the first of them */
-    uint32_t *pixel_done;          /* multi-frame (in-place) launches: per pixel of `out`, how many of the frames are stored
-                                      (zeroed before the launch); NULL for a plain frame */
+    float *partial;                /* multi-frame (in-place) launches: num_frames planes of `partial_plane` pixels, one per frame,
+                                      each receiving that frame's per-pixel mean colour; rt_blend_kernel folds them into `out`.
+                                      NULL for a plain frame */
+    int64_t partial_plane;
     /* tile assignment */
     int32_t band_rows, band_first, band_stride, compact;
     int32_t tiles_x;               /* 8x8 tiles per row of tiles */

@@ -30,8 +30,8 @@
  *  - RNG state, ray, throughput and accumulators live in registers;
  *  - one launch can render several consecutive progressive frames (rt_render_device_batch): the
  *    tickets of frame k + 1 follow those of frame k, so free waves start the next frame while the
- *    last expensive tiles of a frame finish; a pixel's frames are blended in order through a
- *    per-pixel counter (rt_pixel.h, px_finish_pixel).
+ *    last expensive tiles of a frame finish; every frame stores its per-pixel mean in a plane of
+ *    its own and rt_blend_kernel (below) folds the planes into the frame buffer in frame order.
  *
  * The per-pixel sections (shade / fetch / generate, the primitive tests) are in rt_pixel.h; this
  * file has the two kernels built from them - rt_render_kernel (the default) and the opt-in
@@ -144,8 +144,6 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
          * in batches: without a mesh the lanes holding one wait until `shade_batch` of them
          * do, or nobody else can move, while the others go on generating; with a mesh the
          * traversal loop below already yields in batches (`ready_break`). */
-        /* (multi-frame launches) a finished pixel whose previous frame was not stored yet: try again */
-        if (p.mode == M_BLEND) px_finish_pixel(p, a, f);
         if (p.mode == M_SHADE && p.best_obj < 0) px_shade_miss(p, a, f);
         {
             const int n_hit = __popcll(__ballot(p.mode == M_SHADE));
@@ -200,7 +198,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                  * lane (generate, fetch, next mesh, a miss) for one of `ready_break` */
                 const bool is_hit = p.mode == M_SHADE && p.best_obj >= 0;
                 const int n_hit = __popcll(__ballot(is_hit));
-                const int n_light = __popcll(__ballot(p.mode != M_WAIT && p.mode != M_DONE && p.mode != M_BLEND && !is_hit));
+                const int n_light = __popcll(__ballot(p.mode != M_WAIT && p.mode != M_DONE && !is_hit));
                 if (n_hit + n_light > 0 && (n_active < a.work_threshold || n_hit >= a.hit_break || n_light >= a.ready_break)) break;
 #if defined(RT_COSTMAP) && RT_COSTMAP == 2
                 p.c_wsteps += 1;      /* wave-level macro steps this lane lived through */
@@ -290,8 +288,6 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
         }
 
         if (__ballot(p.mode != M_DONE) == 0ull) break;
-        /* nothing but pixels waiting for their previous frame: give the waves that hold it the SIMD */
-        if (__ballot(p.mode != M_DONE && p.mode != M_BLEND) == 0ull) __builtin_amdgcn_s_sleep(8);
     }
     RT_STATS_FLUSH();
 }
@@ -473,8 +469,6 @@ __global__ __launch_bounds__(NT) void rt_render_pool_kernel(const rt_kernel_args
             }
             p.mode = p.next_mesh >= a.num_meshes ? M_SHADE : M_MESH;
         }
-        /* (multi-frame launches) a finished pixel whose previous frame was not stored yet: try again */
-        if (p.mode == M_BLEND) px_finish_pixel(p, a, f);
         const int n_live = __popcll(__ballot(p.mode != M_DONE));
         int n_ready = __popcll(__ballot(p.mode == M_SHADE || p.mode == M_MESH || p.mode == M_GEN || p.mode == M_FETCH));
         const int half_live = (n_live + 1) >> 1;
@@ -682,6 +676,29 @@ __global__ __launch_bounds__(NT) void rt_render_pool_kernel(const rt_kernel_args
 #undef REC_BEST
 #undef REC_CUR
 #undef REC_META
+}
+
+/* The sequential part of a multi-frame launch (src/raytracer.cu:109-112, once per frame): the image
+ * after frame n is (c_n + image * n) / (n + 1), c_n = that frame's per-pixel mean (plane n - frame_num
+ * of `partial`).  In place on `frame`; its content is used only when frame_num > 0. */
+__global__ void rt_blend_kernel(const float *partial, long long plane_floats, int num_frames, int frame_num, float *frame, long long n_floats)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_floats) return;
+    float r = frame_num > 0 ? frame[i] : 0.0f;
+    for (int k = 0; k < num_frames; k++) {
+        const int n = frame_num + k;
+        const float previous_sum = r * (float)n;
+        r = (partial[(long long)k * plane_floats + i] + previous_sum) / (float)(n + 1);
+    }
+    frame[i] = r;
+}
+
+extern "C" hipError_t rt_launch_blend(const float *partial, long long plane_floats, int num_frames, int frame_num, float *frame, long long n_floats, hipStream_t stream)
+{
+    const long long blocks = (n_floats + 255) / 256;
+    hipLaunchKernelGGL(rt_blend_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, partial, plane_floats, num_frames, frame_num, frame, n_floats);
+    return hipGetLastError();
 }
 
 /* float -> RGBA8 of src/main.cu:343-371 */

@@ -20,7 +20,6 @@
 /* 16-byte vector for LDS / global accesses: a single ds_read_b128 / global_load_dwordx4 each
  * (a struct of four floats gets split into narrower loads by the optimiser) */
 typedef float v4f __attribute__((ext_vector_type(4)));
-typedef float v3f __attribute__((ext_vector_type(3)));
 
 struct V3 { float x, y, z; };
 
@@ -128,8 +127,7 @@ __device__ __forceinline__ bool quad_test(const v4f *tris, int first, V3 o, V3 d
 }
 
 /* lane states of the render loop */
-enum { M_FETCH = 0, M_GEN = 1, M_MESH = 2, M_WAIT = 3, M_SHADE = 4, M_DONE = 5,
-       M_BLEND = 6 /* samples done; the previous frame of this pixel (same launch) is not stored yet */ };
+enum { M_FETCH = 0, M_GEN = 1, M_MESH = 2, M_WAIT = 3, M_SHADE = 4, M_DONE = 5 };
 
 /* per-lane pixel state (registers) */
 struct Px {
@@ -194,15 +192,13 @@ __device__ __forceinline__ void frame_init(Frame &f, const rt_kernel_args &a)
 /* A pixel's samples are done: blend with the previous frame and store (src/raytracer.cu:107-112,
  * :133-135).
  *
- * Multi-frame launches (rt_kernel_args.pixel_done != NULL) render consecutive progressive frames of one
+ * Multi-frame launches (rt_kernel_args.partial != NULL) render consecutive progressive frames of one
  * view in ONE launch: every frame has its own seed, so frame k+1 of a pixel can be traced while
  * frame k of the same pixel is still being traced by another wave - the only thing that is
- * sequential is this blend, (c + prev * n) / (n + 1) with prev = the pixel's value after frame k.
- * The frame buffer is updated in place and `pixel_done[pixel]` counts the frames stored so far; a
- * lane that arrives early parks in M_BLEND (the wave goes on with its other lanes) and tries again.
- * Waves on other XCDs do not share an L2 with this one: the pixel and its counter are written and
- * read with agent-scope (sc1) accesses, the counter after the stores have drained
- * (MI355X_MICROARCH.md, inter-workgroup visibility). */
+ * sequential is the blend, (c + prev * n) / (n + 1) with prev = the pixel's value after frame k.
+ * So each frame only stores c, the mean of its own samples, into its plane of a scratch buffer
+ * (plain stores, no ordering between frames needed), and a small kernel launched behind this one
+ * (rt_blend_kernel) folds the planes into the frame buffer in frame order. */
 __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, const Frame &f)
 {
     const V3 c = p.colour / (float)f.spp;
@@ -212,34 +208,19 @@ __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, 
         out_row = ((band - a.band_first) / a.band_stride) * a.band_rows + (p.py - band * a.band_rows);
     }
     const size_t pixel = (size_t)out_row * (size_t)f.W + (size_t)p.px;
-    float *dst = a.out + pixel * 3;
-    const int frame = (int)(p.frame_steps & 15u);
-    if (a.tile_cost && (a.pixel_done == nullptr || frame == 0 || __hip_atomic_load(a.pixel_done + pixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)frame)) {
-        /* (first launch of a view) what this pixel cost, charged to its tile; not when the lane is about to park */
+    if (a.tile_cost) {
+        /* (first launch of a view) what this pixel cost, charged to its tile */
         const int band = p.py / a.band_rows;
         const int tile = ((band - a.band_first) / a.band_stride) * f.tiles_per_band + ((p.py - band * a.band_rows) >> 3) * a.tiles_x + (p.px >> 3);
         atomicAdd(a.tile_cost + tile, p.frame_steps >> 4);
     }
-    if (a.pixel_done) {
-        const int n = a.frame_num + frame;
-        V3 previous = v3(0.f, 0.f, 0.f);
-        if (frame > 0) {
-            if (__hip_atomic_load(a.pixel_done + pixel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint32_t)frame) { p.mode = M_BLEND; return; }
-            /* the three floats in ONE agent-scope access (an sc1 dword is a fabric transaction of its own) */
-            v3f pv;
-            asm volatile("global_load_dwordx3 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(pv) : "v"(dst) : "memory");
-            previous = v3(pv.x, pv.y, pv.z);
-        } else if (n > 0) {
-            previous = v3(dst[0], dst[1], dst[2]);                 /* what the caller put there before the launch */
-        }
-        const V3 res = (c + previous * (float)n) / (float)(n + 1);
-        v3f rv;
-        rv.x = res.x; rv.y = res.y; rv.z = res.z;
-        asm volatile("global_store_dwordx3 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : : "v"(dst), "v"(rv) : "memory");
-        __hip_atomic_store(a.pixel_done + pixel, (uint32_t)(frame + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        p.mode = M_FETCH;
+    p.mode = M_FETCH;
+    if (a.partial) {
+        float *dst = a.partial + ((size_t)(p.frame_steps & 15u) * a.partial_plane + pixel) * 3;
+        dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
         return;
     }
+    float *dst = a.out + pixel * 3;
     const int array_index = (p.py * f.W + p.px) * 3;
     V3 previous = v3(0.f, 0.f, 0.f);
     if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
@@ -249,7 +230,6 @@ __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, 
     res = v3(__uint_as_float(RT_COSTMAP == 2 ? p.c_wsteps : p.c_steps), __uint_as_float(p.c_t0), __uint_as_float((unsigned)wall_clock64()));
 #endif
     dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
-    p.mode = M_FETCH;
 }
 
 /* the end of a sample (src/raytracer.cu:102-105): add it to the pixel, restart from a copy of the
@@ -469,7 +449,7 @@ __device__ __forceinline__ void px_fetch(Px &p, Chunk &ch, const rt_kernel_args 
         if (p.sample >= f.spp) {
             const float q = 0.0f / (float)f.spp;               /* NaN for spp == 0, like the reference */
             p.colour = v3(q, q, q) * (float)f.spp;             /* px_finish_pixel divides by spp again: q either way */
-            px_finish_pixel(p, a, f);                          /* M_FETCH: takes another pixel next time round (or M_BLEND) */
+            px_finish_pixel(p, a, f);                          /* M_FETCH: takes another pixel next time round */
         } else {
             p.mode = M_GEN;
         }
