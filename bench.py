@@ -91,7 +91,7 @@ def cpu_baseline(rt, objs, sky, W, H, limit, spp_full, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--scene", default="monkey", choices=["three_sphere", "cube", "monkey"])
     ap.add_argument("--width", type=int, default=1920)

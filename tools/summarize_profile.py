@@ -3,7 +3,7 @@ import collections, csv, glob, json, os, sys
 d = sys.argv[1]
 print("# rocprofv3 summary of", d)
 for f in glob.glob(os.path.join(d, "stats", "*", "*_kernel_stats.csv")):
-    print("\n## kernel stats (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-frame-by-frame-leg)")
+    print("\n## kernel stats (rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-frame-by-frame-leg)")
     for i, row in enumerate(csv.reader(open(f))):
         if i < 6:
             print(",".join(row))
@@ -27,7 +27,7 @@ for f in sorted(glob.glob(os.path.join(d, "pmc*", "*", "*_counter_collection.csv
         if int(row["Dispatch_Id"]) == last:
             t[row["Counter_Name"]] += float(row["Counter_Value"])
             n[row["Counter_Name"]] += 1
-print("\n## PMC counters, one launch of rt_render_kernel (monkey 1920x1080, 1024 spp, 8 bounces, 3 progressive frames in the launch), summed over the device")
+print("\n## PMC counters, one launch of rt_render_kernel (monkey 1920x1080, 1024 spp, 8 bounces, 8 progressive frames in the launch), summed over the device")
 for k in sorted(t):
     print("%-26s %.6g" % (k, t[k]))
 if t.get("SQ_ACTIVE_INST_VALU"):
