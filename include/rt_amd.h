@@ -11,6 +11,13 @@
  * single host thread with blocking launches, src/dispatch.cu:139-141).  There are no hidden
  * globals: scene, camera and settings are arguments (the reference's __constant__ symbols
  * make it non-reentrant).
+ *
+ * One launch in flight per context.  A context owns the scratch its launches use (tile ticket
+ * counter, the per-frame planes of a multi-frame launch, tile order and costs, timing events), so
+ * the device-buffer entry points keep a context's launches in order: a launch on a different
+ * stream than the previous one is queued behind it (hipStreamWaitEvent), it does not overlap it.
+ * To overlap renders on one GPU use two contexts; to use several GPUs use one context per GPU
+ * (rt_render_multi below, or one process per GPU).
  */
 #ifndef RT_AMD_H
 #define RT_AMD_H
@@ -184,7 +191,7 @@ rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *
                            int32_t time_ms, int32_t frame_num, const rt_tile_spec *tiles,
                            const float *d_prev, float *d_out, void *hip_stream);
 
-/* n_frames (1..16) consecutive progressive frames of one view in ONE launch: what the reference's main
+/* n_frames (1..32) consecutive progressive frames of one view in ONE launch: what the reference's main
  * loop (src/main.cu:415-431) does with one render() per frame - frames frame_num, frame_num + 1, ...,
  * seeded with times_ms[0..n_frames) - accumulated IN PLACE in d_frame (same layout as d_out above; when
  * frame_num > 0 its content is the image after frame_num - 1, otherwise it is ignored).  The result is
@@ -203,6 +210,41 @@ int32_t rt_tile_owned_rows(const rt_tile_spec *tiles, int32_t height);
 /* Kernel timing by HIP events recorded on the launch stream around the render kernel of the
  * most recent rt_render / rt_render_device call; blocks until that kernel has finished. */
 rt_status rt_last_kernel_ms(rt_ctx *ctx, float *ms);
+/* Blocks until the most recent launch of this context has finished and returns its status: the
+ * cudaDeviceSynchronize + cudaPeekAtLastError pair of src/dispatch.cu:141,161 for callers of the
+ * asynchronous device-buffer entry points.  RT_ERR_HIP if the (opt-in) pooled kernel abandoned the frame. */
+rt_status rt_ctx_synchronize(rt_ctx *ctx);
+
+/* ---- several GPUs of one node from one host thread ---------------------------------------------
+ * What run_ray_tracer (src/dispatch.cu:127-153) does on one device, n devices do for the bands they
+ * own: rank i of n_ranks renders the bands b with b % n_ranks == i (a pixel depends
+ * only on its own coordinates, seed and previous value, so any partition gives the single-GPU image bit
+ * for bit) on its own context, asynchronously; the band buffers travel to ranks[0]'s GPU with one peer
+ * copy per rank (xGMI) and are de-interleaved there.  There is no reduction, hence no collective.
+ * Every rank needs the scene committed on ITS context; a context may appear once. */
+typedef struct rt_rank {
+    rt_ctx *ctx;
+    const rt_scene *scene;
+} rt_rank;
+
+/* render() src/dispatch.cu:156-163 for a node, host-buffer form: n_frames passes of the main loop body
+ * (frame i seeded with times_ms[i]) accumulated into previous_render; *frame_num advances by n_frames.
+ * Same image as rt_render_frames on one GPU. */
+rt_status rt_render_multi(const rt_rank *ranks, int32_t n_ranks, const rt_camera *cam, const rt_render_settings *rs,
+                          const int32_t *times_ms, int32_t n_frames, int32_t *frame_num, float *previous_render);
+/* Device-buffer form: d_frame is a full W*H*3 frame on ranks[0]'s GPU, updated in place (its content is
+ * the image after frame_num - 1 when frame_num > 0, ignored otherwise); bands of band_rows rows (a
+ * positive multiple of 8).  Asynchronous: the frame is complete in the order of hip_stream (a stream of
+ * ranks[0]'s GPU, NULL = default stream); rt_ctx_synchronize on each rank reports kernel errors. */
+rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_ranks, const rt_camera *cam, const rt_render_settings *rs,
+                                 const int32_t *times_ms, int32_t n_frames, int32_t frame_num, int32_t band_rows,
+                                 float *d_frame, void *hip_stream);
+/* The exchange step alone, for callers that launch the ranks themselves (rt_render_device[_batch] with a
+ * compact tile spec): the band buffer d_bands of the rank `src_tiles` describes, on src's GPU, lands in the
+ * full frame d_frame on root's GPU - one peer copy + a de-interleave on root_stream - ordered behind src's
+ * most recent launch. */
+rt_status rt_gather(rt_ctx *root, float *d_frame, int32_t width, int32_t height, rt_ctx *src, const float *d_bands,
+                    const rt_tile_spec *src_tiles, void *root_stream);
 
 /* float -> RGBA8 display conversion of src/main.cu:343-371 (int(px*255), clamp, alpha 255),
  * on the device: d_rgb W*H*3 floats -> d_rgba W*H*4 bytes */

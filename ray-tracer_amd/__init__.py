@@ -48,6 +48,10 @@ class rt_tile_spec(C.Structure):
     _fields_ = [("band_rows", C.c_int32), ("band_first", C.c_int32), ("band_stride", C.c_int32), ("compact", C.c_int32)]
 
 
+class rt_rank(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("scene", C.c_void_p)]
+
+
 class rt_scene_info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_objects", "num_triangles", "num_nodes", "lds_bytes", "scene_in_lds", "threads_per_block", "stack_entries")]
 
@@ -72,6 +76,7 @@ ABI_SYMBOLS = [
     "rt_obj_num_triangles", "rt_obj_get_triangles", "rt_camera_default", "rt_camera_make",
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_commit", "rt_scene_destroy",
     "rt_scene_get_info", "rt_render", "rt_render_frames", "rt_render_device", "rt_render_device_batch", "rt_tile_owned_rows", "rt_last_kernel_ms",
+    "rt_ctx_synchronize", "rt_render_multi", "rt_render_multi_device", "rt_gather",
     "rt_to_rgba8_device", "rt_debug_flatten", "rt_debug_read_stats", "rt_debug_eval", "rt_version",
 ]
 
@@ -162,6 +167,12 @@ def lib():
                                          C.POINTER(rt_tile_spec), vp, vp]
     L.rt_tile_owned_rows.argtypes = [C.POINTER(rt_tile_spec), C.c_int32]
     L.rt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.rt_ctx_synchronize.argtypes = [vp]
+    L.rt_render_multi.argtypes = [C.POINTER(rt_rank), C.c_int32, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.POINTER(C.c_int32), C.c_int32,
+                                  C.POINTER(C.c_int32), fp]
+    L.rt_render_multi_device.argtypes = [C.POINTER(rt_rank), C.c_int32, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.POINTER(C.c_int32), C.c_int32,
+                                         C.c_int32, C.c_int32, vp, vp]
+    L.rt_gather.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp, C.POINTER(rt_tile_spec), vp]
     L.rt_to_rgba8_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
     L.rt_debug_flatten.argtypes = [vp, C.POINTER(rt_flat_view)]
     L.rt_debug_read_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
@@ -524,6 +535,10 @@ class Context:
         self._check(lib().rt_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def synchronize(self):
+        """waits for this context's most recent launch; raises if the kernel reported an incomplete frame"""
+        self._check(lib().rt_ctx_synchronize(self._h))
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):
@@ -599,6 +614,39 @@ def render_device_batch(ctx, scene, camera, render_data, times_ms, frame_num, d_
     t = (C.c_int32 * len(times_ms))(*[int(x) for x in times_ms])
     ctx._check(lib().rt_render_device_batch(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), t, len(times_ms), int(frame_num),
                                             C.byref(ts), C.c_void_p(d_frame), C.c_void_p(stream or 0)))
+
+
+def _ranks(ctxs, scenes):
+    arr = (rt_rank * len(ctxs))()
+    for i, (c, s) in enumerate(zip(ctxs, scenes)):
+        arr[i].ctx, arr[i].scene = c._h, s._h
+    return arr
+
+
+def render_multi(ctxs, scenes, camera, render_data, data, times_ms):
+    """render() for a node (rt_render_multi): rank i = (ctxs[i], scenes[i]) renders the bands b % n == i on its
+    own GPU; the image lands in data.previous_render like render_frames on one GPU."""
+    fn = C.c_int32(data.frame_num)
+    buf = data.previous_render
+    assert buf.dtype == np.float32 and buf.flags["C_CONTIGUOUS"]
+    t = (C.c_int32 * len(times_ms))(*[int(x) for x in times_ms])
+    ctxs[0]._check(lib().rt_render_multi(_ranks(ctxs, scenes), len(ctxs), C.byref(camera.c), C.byref(render_data.c), t, len(times_ms),
+                                         C.byref(fn), buf.ctypes.data_as(C.POINTER(C.c_float))))
+    data.frame_num = fn.value
+    return buf
+
+
+def render_multi_device(ctxs, scenes, camera, render_data, times_ms, frame_num, d_frame, band_rows=8, stream=None):
+    """device-buffer form (rt_render_multi_device): d_frame is a full frame on ctxs[0]'s GPU, updated in place"""
+    t = (C.c_int32 * len(times_ms))(*[int(x) for x in times_ms])
+    ctxs[0]._check(lib().rt_render_multi_device(_ranks(ctxs, scenes), len(ctxs), C.byref(camera.c), C.byref(render_data.c), t, len(times_ms),
+                                                int(frame_num), int(band_rows), C.c_void_p(d_frame), C.c_void_p(stream or 0)))
+
+
+def gather(root, d_frame, width, height, src, d_bands, band_rows, band_first, band_stride, stream=None):
+    """the exchange step alone (rt_gather): src's compact band buffer -> the full frame on root's GPU"""
+    ts = rt_tile_spec(int(band_rows), int(band_first), int(band_stride), 1)
+    root._check(lib().rt_gather(root._h, C.c_void_p(d_frame), int(width), int(height), src._h, C.c_void_p(d_bands), C.byref(ts), C.c_void_p(stream or 0)))
 
 
 def debug_eval(ctx, op, bits):

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,6 +35,19 @@ struct rt_ctx {
     uint32_t *tile_counter = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool have_timing = false;
+    /* The launch scratch below (ticket counter, per-frame planes, tile order / costs, the two events) is
+     * per context, so launches of one context are kept in order: a launch on another stream than the
+     * previous one first waits for that one's stop event (one launch in flight per context). */
+    hipStream_t last_stream = nullptr;
+    bool launched = false;
+    /* multi-GPU entry points (rt_render_multi*): this rank's compact band buffer, its stream and "bands
+     * are in the root's staging area" event; on the root also the staging area for every rank's bands */
+    float *d_bands = nullptr;
+    size_t bands_cap = 0;                /* floats */
+    float *d_stage = nullptr;
+    size_t stage_cap = 0;                /* floats */
+    hipStream_t multi_stream = nullptr;
+    hipEvent_t ev_multi = nullptr;
     /* persistent frame buffers for the host-buffer entry point */
     float *d_prev = nullptr, *d_out = nullptr;
     size_t frame_bytes = 0;
@@ -155,6 +169,10 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
     if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+    if (ctx->d_bands) (void)hipFree(ctx->d_bands);
+    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    if (ctx->multi_stream) (void)hipStreamDestroy(ctx->multi_stream);
+    if (ctx->ev_multi) (void)hipEventDestroy(ctx->ev_multi);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;
@@ -169,8 +187,8 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
     rt_scene *s = new (std::nothrow) rt_scene();
     if (!s) return RT_ERR_NOMEM;
     s->ctx = ctx;
-    static uint32_t next_uid = 1;
-    s->uid = next_uid++;
+    static std::atomic<uint32_t> next_uid{1};
+    s->uid = next_uid.fetch_add(1);
     std::string err = rt_flatten(*b, s->flat);
     if (!err.empty()) { delete s; return set_err(ctx, RT_ERR_UNSUPPORTED, err); }
 
@@ -287,6 +305,8 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
         return set_err(ctx, RT_ERR_INVALID, "bad tile spec (band_rows must be a positive multiple of 8, 0 <= band_first < band_stride)");
     hipStream_t stream = (hipStream_t)hip_stream;
     RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    /* one launch in flight per context: the scratch is shared (see rt_ctx) */
+    if (ctx->launched && ctx->last_stream != stream) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_stop, 0), "ordering the launch behind the previous one");
 
     rt_kernel_args a;
     std::memset(&a, 0, sizeof a);
@@ -392,8 +412,12 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
                 a.tile_cost = ctx->d_tile_cost;
                 ctx->cost_state = 1;
             } else if (ctx->cost_state == 1) {
+                /* on the launch stream: the launch that collected the costs ran on it (or this stream has
+                 * been ordered behind it above), and a blocking copy on the null stream would not wait for
+                 * a non-blocking stream's kernel */
                 std::vector<uint32_t> cost(n);
-                RT_HIP(ctx, hipMemcpy(cost.data(), ctx->d_tile_cost, (size_t)n * 4, hipMemcpyDeviceToHost), "reading tile costs");
+                RT_HIP(ctx, hipMemcpyAsync(cost.data(), ctx->d_tile_cost, (size_t)n * 4, hipMemcpyDeviceToHost, stream), "reading tile costs");
+                RT_HIP(ctx, hipStreamSynchronize(stream), "reading tile costs");
                 std::vector<uint32_t> idx(ctx->order_host);
                 std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
                 uint32_t top = (uint32_t)ctx->heavy_top < n ? (uint32_t)ctx->heavy_top : n;
@@ -404,7 +428,9 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
                 const uint32_t st = ctx->tile_scatter ? coprime_stride(top) : 1u;
                 for (uint32_t i = 0; i < top; i++) { const uint32_t t = idx[(size_t)(((uint64_t)i * st) % top)]; merged.push_back(t); taken[t] = 1; }
                 for (uint32_t t : ctx->order_host) if (!taken[t]) merged.push_back(t);
-                RT_HIP(ctx, hipMemcpy(ctx->d_tile_order, merged.data(), (size_t)n * 4, hipMemcpyHostToDevice), "uploading tile order");
+                /* the stream is idle (synchronised above): nothing is indexing the old order any more */
+                RT_HIP(ctx, hipMemcpyAsync(ctx->d_tile_order, merged.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream), "uploading tile order");
+                RT_HIP(ctx, hipStreamSynchronize(stream), "uploading tile order");     /* `merged` is a local */
                 ctx->order_host.swap(merged);
                 ctx->order_num_heavy = (int)top;
                 ctx->cost_state = 2;
@@ -488,6 +514,8 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream), "recording stop event");
     ctx->have_timing = true;
+    ctx->launched = true;
+    ctx->last_stream = stream;
     return RT_OK;
 }
 
@@ -507,7 +535,7 @@ extern "C" rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, 
                                             const int32_t *times_ms, int32_t n_frames, int32_t frame_num, const rt_tile_spec *tiles,
                                             float *d_frame, void *hip_stream)
 {
-    if (!times_ms || n_frames < 1 || n_frames > RT_MAX_BATCH_FRAMES) return set_err(ctx, RT_ERR_INVALID, "n_frames must be 1..16");
+    if (!times_ms || n_frames < 1 || n_frames > RT_MAX_BATCH_FRAMES) return set_err(ctx, RT_ERR_INVALID, "n_frames must be 1..32");
     if (frame_num < 0) return set_err(ctx, RT_ERR_INVALID, "bad frame number");
     return render_frames(ctx, scene, cam, rs, times_ms, n_frames, frame_num, tiles, nullptr, d_frame, hip_stream, true);
 }
@@ -604,6 +632,245 @@ extern "C" rt_status rt_render_frames(rt_ctx *ctx, const rt_scene *scene, const 
     RT_HIP(ctx, hipDeviceSynchronize(), "render kernel");
     rt_status st = check_kernel_flag(ctx);
     if (st != RT_OK) return st;
+    RT_HIP(ctx, hipMemcpy(previous_render, ctx->d_out, bytes, hipMemcpyDeviceToHost), "copying frame to host");
+    *frame_num += n_frames;
+    RT_HIP(ctx, hipPeekAtLastError(), "final check after render");
+    return RT_OK;
+}
+
+/* waits for the most recent launch of this context and reports a frame the pooled kernel gave up on */
+extern "C" rt_status rt_ctx_synchronize(rt_ctx *ctx)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    if (!ctx->launched) return RT_OK;
+    RT_HIP(ctx, hipEventSynchronize(ctx->ev_stop), "waiting for render kernel");
+    return check_kernel_flag(ctx);
+}
+
+/* =============================================================================================
+ * Multi-GPU from one host thread (SURVEY.md §8(b) "rt_gather", §8(e)): rank i of n renders the
+ * bands b with b % n == i on its own GPU into a compact band buffer; the bands travel to the
+ * root's GPU with one peer copy per rank (xGMI) and are de-interleaved there.  No collective is
+ * needed: nothing is reduced, every pixel has one owner.
+ * ============================================================================================= */
+namespace {
+
+struct BandLayout {
+    int W = 0, H = 0, band_rows = 8, n = 1;
+    size_t chunk() const { return (size_t)band_rows * (size_t)W * 3; }            /* floats per band */
+    int bands_total() const { return (H + band_rows - 1) / band_rows; }
+    int bands_of(int i) const { const int t = bands_total(); return t > i ? (t - i + n - 1) / n : 0; }
+    size_t floats_of(int i) const { return (size_t)bands_of(i) * chunk(); }
+};
+
+/* bands of rank i between a full frame and a compact buffer, both on the current device.  The last band
+ * of the image may be ragged: only its valid rows exist in the full frame. */
+hipError_t copy_bands(const BandLayout &L, int i, float *full, float *compact, bool to_full, hipStream_t stream)
+{
+    const int nb = L.bands_of(i);
+    if (nb == 0) return hipSuccess;
+    const size_t chunk_bytes = L.chunk() * 4, full_pitch = chunk_bytes * (size_t)L.n;
+    const int last_band = i + (nb - 1) * L.n;
+    const int last_rows = std::min(L.band_rows, L.H - last_band * L.band_rows);
+    const int whole = last_rows == L.band_rows ? nb : nb - 1;
+    float *full0 = full + (size_t)i * L.chunk();
+    hipError_t e = hipSuccess;
+    if (whole > 0) {
+        e = to_full ? hipMemcpy2DAsync(full0, full_pitch, compact, chunk_bytes, chunk_bytes, (size_t)whole, hipMemcpyDeviceToDevice, stream)
+                    : hipMemcpy2DAsync(compact, chunk_bytes, full0, full_pitch, chunk_bytes, (size_t)whole, hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
+    if (whole < nb) {
+        const size_t bytes = (size_t)last_rows * (size_t)L.W * 12;
+        float *f = full + (size_t)last_band * L.chunk(), *c = compact + (size_t)(nb - 1) * L.chunk();
+        e = to_full ? hipMemcpyAsync(f, c, bytes, hipMemcpyDeviceToDevice, stream) : hipMemcpyAsync(c, f, bytes, hipMemcpyDeviceToDevice, stream);
+    }
+    return e;
+}
+
+rt_status grow(rt_ctx *ctx, float **buf, size_t *cap, size_t need, const char *what)
+{
+    if (*cap >= need && *buf) return RT_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *cap = 0;
+    RT_HIP(ctx, hipMalloc((void **)buf, (need ? need : 4) * 4), what);
+    *cap = need;
+    return RT_OK;
+}
+
+rt_status multi_prepare(rt_ctx *ctx)
+{
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    if (!ctx->multi_stream) RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->multi_stream, hipStreamNonBlocking), "creating the rank's stream");
+    if (!ctx->ev_multi) RT_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_multi, hipEventDisableTiming), "creating the rank's event");
+    return RT_OK;
+}
+
+/* device-to-device bytes between two contexts' GPUs (a plain copy when they share one), on a stream of
+ * the CURRENT device */
+hipError_t copy_between(float *dst, int dst_dev, const float *src, int src_dev, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return hipSuccess;
+    if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+    return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, stream);
+}
+
+}  // namespace
+
+/* The exchange step alone: the compact band buffer `d_bands` of the rank described by `src_tiles`
+ * (on src's GPU) lands in the full frame `d_frame` on root's GPU.  Ordered behind src's most recent
+ * launch; the frame is complete in `root_stream` order. */
+extern "C" rt_status rt_gather(rt_ctx *root, float *d_frame, int32_t width, int32_t height, rt_ctx *src, const float *d_bands,
+                               const rt_tile_spec *src_tiles, void *root_stream)
+{
+    if (!root || !src || !d_frame || !d_bands || !src_tiles) return set_err(root, RT_ERR_INVALID, "null argument");
+    if (width <= 0 || height <= 0 || src_tiles->band_rows <= 0 || (src_tiles->band_rows & 7) || src_tiles->band_stride <= 0 ||
+        src_tiles->band_first < 0 || src_tiles->band_first >= src_tiles->band_stride)
+        return set_err(root, RT_ERR_INVALID, "bad tile spec");
+    BandLayout L;
+    L.W = width; L.H = height; L.band_rows = src_tiles->band_rows; L.n = src_tiles->band_stride;
+    const int i = src_tiles->band_first;
+    rt_status st = multi_prepare(root);
+    if (st != RT_OK) return st;
+    hipStream_t s0 = (hipStream_t)root_stream;
+    const float *from = d_bands;
+    if (src->device != root->device) {
+        /* one peer copy of the whole band buffer into the root's staging area, behind src's last launch */
+        size_t off = 0;
+        for (int r = 0; r < i; r++) off += L.floats_of(r);
+        size_t total = off;
+        for (int r = i; r < L.n; r++) total += L.floats_of(r);
+        if (root->stage_cap < total) {
+            RT_HIP(root, hipStreamSynchronize(s0), "waiting for the staging area");
+            if ((st = grow(root, &root->d_stage, &root->stage_cap, total, "allocating the gather staging area")) != RT_OK) return st;
+        }
+        if ((st = multi_prepare(src)) != RT_OK) return st;
+        if (src->launched) RT_HIP(src, hipStreamWaitEvent(src->multi_stream, src->ev_stop, 0), "ordering the gather behind the render");
+        RT_HIP(src, copy_between(root->d_stage + off, root->device, d_bands, src->device, L.floats_of(i) * 4, src->multi_stream), "copying bands to the root GPU");
+        RT_HIP(src, hipEventRecord(src->ev_multi, src->multi_stream), "recording the gather event");
+        RT_HIP(root, hipSetDevice(root->device), "selecting device");
+        RT_HIP(root, hipStreamWaitEvent(s0, src->ev_multi, 0), "ordering the de-interleave behind the copy");
+        from = root->d_stage + off;
+    } else if (src->launched) {
+        RT_HIP(root, hipStreamWaitEvent(s0, src->ev_stop, 0), "ordering the gather behind the render");
+    }
+    RT_HIP(root, copy_bands(L, i, d_frame, const_cast<float *>(from), true, s0), "de-interleaving bands");
+    return RT_OK;
+}
+
+/* n_frames consecutive progressive frames over n_ranks GPUs, accumulated in place in d_frame (a full
+ * frame on ranks[0]'s GPU).  Replaces run_ray_tracer src/dispatch.cu:127-153 for a node: what one
+ * device did there, n do here, each for the bands it owns. */
+extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_ranks, const rt_camera *cam, const rt_render_settings *rs,
+                                            const int32_t *times_ms, int32_t n_frames, int32_t frame_num, int32_t band_rows,
+                                            float *d_frame, void *hip_stream)
+{
+    if (!ranks || n_ranks < 1 || !ranks[0].ctx) return RT_ERR_INVALID;
+    rt_ctx *root = ranks[0].ctx;
+    if (!cam || !rs || !times_ms || !d_frame || n_frames < 1 || frame_num < 0) return set_err(root, RT_ERR_INVALID, "null argument");
+    if (cam->width <= 0 || cam->height <= 0 || band_rows <= 0 || (band_rows & 7)) return set_err(root, RT_ERR_INVALID, "bad image size or band_rows (a positive multiple of 8)");
+    for (int i = 0; i < n_ranks; i++) {
+        if (!ranks[i].ctx || !ranks[i].scene || ranks[i].scene->ctx != ranks[i].ctx) return set_err(root, RT_ERR_INVALID, "rank without a context, or a scene committed on another context");
+        for (int j = 0; j < i; j++) if (ranks[j].ctx == ranks[i].ctx) return set_err(root, RT_ERR_INVALID, "a context may appear once (its launch scratch is not shared between ranks)");
+    }
+    BandLayout L;
+    L.W = cam->width; L.H = cam->height; L.band_rows = band_rows; L.n = n_ranks;
+    hipStream_t s0 = (hipStream_t)hip_stream;
+    rt_status st;
+    size_t total = 0;
+    std::vector<size_t> off(n_ranks);
+    for (int i = 0; i < n_ranks; i++) { off[i] = total; total += L.floats_of(i); }
+    if ((st = multi_prepare(root)) != RT_OK) return st;
+    if (root->stage_cap < total) {
+        RT_HIP(root, hipStreamSynchronize(s0), "waiting for the staging area");
+        if ((st = grow(root, &root->d_stage, &root->stage_cap, total, "allocating the gather staging area")) != RT_OK) return st;
+    }
+    for (int i = 0; i < n_ranks; i++) {
+        rt_ctx *c = ranks[i].ctx;
+        if ((st = multi_prepare(c)) != RT_OK) return set_err(root, st, rt_last_error(c));
+        if (c->bands_cap < L.floats_of(i)) {
+            RT_HIP(c, hipStreamSynchronize(c->multi_stream), "waiting for the band buffer");
+            if ((st = grow(c, &c->d_bands, &c->bands_cap, L.floats_of(i), "allocating the band buffer")) != RT_OK) return set_err(root, st, rt_last_error(c));
+        }
+        if (c->device != root->device) {
+            /* direct xGMI copies instead of staging through the host; "already enabled" is fine */
+            (void)hipSetDevice(c->device); (void)hipDeviceEnablePeerAccess(root->device, 0);
+            (void)hipSetDevice(root->device); (void)hipDeviceEnablePeerAccess(c->device, 0);
+            (void)hipGetLastError();
+        }
+    }
+    /* the image so far goes out to its owners */
+    if (frame_num > 0) {
+        RT_HIP(root, hipSetDevice(root->device), "selecting device");
+        for (int i = 0; i < n_ranks; i++) RT_HIP(root, copy_bands(L, i, d_frame, root->d_stage + off[i], false, s0), "interleaving bands");
+        RT_HIP(root, hipEventRecord(root->ev_multi, s0), "recording the scatter event");
+        for (int i = 0; i < n_ranks; i++) {
+            rt_ctx *c = ranks[i].ctx;
+            RT_HIP(c, hipSetDevice(c->device), "selecting device");
+            RT_HIP(c, hipStreamWaitEvent(c->multi_stream, root->ev_multi, 0), "ordering the scatter");
+            RT_HIP(c, copy_between(c->d_bands, c->device, root->d_stage + off[i], root->device, L.floats_of(i) * 4, c->multi_stream), "copying bands to their GPU");
+        }
+    } else {
+        /* frame 0 ignores the buffer's content, but the staging area may still be read by an earlier
+         * call's de-interleave on s0: order the ranks' copies into it behind that */
+        RT_HIP(root, hipSetDevice(root->device), "selecting device");
+        RT_HIP(root, hipEventRecord(root->ev_multi, s0), "recording the start event");
+        for (int i = 0; i < n_ranks; i++) {
+            rt_ctx *c = ranks[i].ctx;
+            RT_HIP(c, hipSetDevice(c->device), "selecting device");
+            RT_HIP(c, hipStreamWaitEvent(c->multi_stream, root->ev_multi, 0), "ordering the ranks behind the caller's stream");
+        }
+    }
+    /* every rank renders its bands (asynchronous launches from this one thread) and sends them back */
+    for (int i = 0; i < n_ranks; i++) {
+        rt_ctx *c = ranks[i].ctx;
+        if (L.bands_of(i) == 0) continue;
+        rt_tile_spec t = {band_rows, i, n_ranks, 1};
+        for (int32_t done = 0; done < n_frames;) {
+            const int32_t k = std::min<int32_t>(n_frames - done, RT_MAX_BATCH_FRAMES);
+            st = rt_render_device_batch(c, ranks[i].scene, cam, rs, times_ms + done, k, frame_num + done, &t, c->d_bands, c->multi_stream);
+            if (st != RT_OK) return set_err(root, st, rt_last_error(c));
+            done += k;
+        }
+        RT_HIP(c, copy_between(root->d_stage + off[i], root->device, c->d_bands, c->device, L.floats_of(i) * 4, c->multi_stream), "copying bands to the root GPU");
+        RT_HIP(c, hipEventRecord(c->ev_multi, c->multi_stream), "recording the gather event");
+    }
+    RT_HIP(root, hipSetDevice(root->device), "selecting device");
+    for (int i = 0; i < n_ranks; i++) {
+        if (L.bands_of(i) == 0) continue;
+        RT_HIP(root, hipStreamWaitEvent(s0, ranks[i].ctx->ev_multi, 0), "ordering the de-interleave behind the copies");
+        RT_HIP(root, copy_bands(L, i, d_frame, root->d_stage + off[i], true, s0), "de-interleaving bands");
+    }
+    return RT_OK;
+}
+
+/* render() src/dispatch.cu:156-163 for a node: host-buffer form of the above */
+extern "C" rt_status rt_render_multi(const rt_rank *ranks, int32_t n_ranks, const rt_camera *cam, const rt_render_settings *rs,
+                                     const int32_t *times_ms, int32_t n_frames, int32_t *frame_num, float *previous_render)
+{
+    if (!ranks || n_ranks < 1 || !ranks[0].ctx) return RT_ERR_INVALID;
+    rt_ctx *ctx = ranks[0].ctx;
+    if (!cam || !frame_num || !previous_render || !times_ms || n_frames < 1) return set_err(ctx, RT_ERR_INVALID, "null argument");
+    if (cam->width <= 0 || cam->height <= 0) return set_err(ctx, RT_ERR_INVALID, "bad image size");
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    const size_t bytes = (size_t)cam->width * (size_t)cam->height * 3 * sizeof(float);
+    if (bytes != ctx->frame_bytes) {
+        if (ctx->d_prev) (void)hipFree(ctx->d_prev);
+        if (ctx->d_out) (void)hipFree(ctx->d_out);
+        ctx->d_prev = ctx->d_out = nullptr;
+        ctx->frame_bytes = 0;
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_prev, bytes), "allocating previous-frame buffer");
+        RT_HIP(ctx, hipMalloc((void **)&ctx->d_out, bytes), "allocating frame buffer");
+        ctx->frame_bytes = bytes;
+    }
+    RT_HIP(ctx, hipMemcpy(ctx->d_out, previous_render, bytes, hipMemcpyHostToDevice), "copying previous frame");
+    rt_status st = rt_render_multi_device(ranks, n_ranks, cam, rs, times_ms, n_frames, *frame_num, 8, ctx->d_out, nullptr);
+    if (st != RT_OK) return st;
+    RT_HIP(ctx, hipStreamSynchronize(nullptr), "render kernels");
+    for (int i = 0; i < n_ranks; i++)
+        if ((st = rt_ctx_synchronize(ranks[i].ctx)) != RT_OK) return set_err(ctx, st, rt_last_error(ranks[i].ctx));
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
     RT_HIP(ctx, hipMemcpy(previous_render, ctx->d_out, bytes, hipMemcpyDeviceToHost), "copying frame to host");
     *frame_num += n_frames;
     RT_HIP(ctx, hipPeekAtLastError(), "final check after render");

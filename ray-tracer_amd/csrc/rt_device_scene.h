@@ -30,7 +30,8 @@
 
 #define RT_BVH_DEPTH 10              /* reference src/objects.cu:786 */
 #define RT_STACK_ENTRIES RT_BVH_DEPTH /* at most one pending sibling per level below the root */
-#define RT_MAX_BATCH_FRAMES 16        /* frames one launch can render */
+#define RT_FRAME_BITS 5               /* a pixel keeps the index of its frame within the launch in this many bits */
+#define RT_MAX_BATCH_FRAMES (1 << RT_FRAME_BITS)   /* frames one launch can render */
 #define RT_INF_F 1073741824.0f       /* reference `1 << 31 - 1` == 1 << 30, src/objects.cu:6 */
 #define RT_EPS_F 0.000001f           /* FLOAT_PRECISION_ERROR src/objects.cu:7 */
 

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                 RT_LAP(TM_CTL);
                 if (p.mode == M_WAIT) {
                     RT_STAT(ST_WORK_ITER);
-                    p.frame_steps += 16u;             /* one more traversal macro step (bits 31..4) */
+                    p.frame_steps += (unsigned)RT_MAX_BATCH_FRAMES;   /* one more traversal macro step (the bits above the frame index) */
                     /* one macro step: descend to a leaf (or run out of children), test the
                      * leaf's triangles, pop the next deferred sibling.  The lane's whole
                      * traversal state is `cur` (+ the stack): an internal node to descend from,

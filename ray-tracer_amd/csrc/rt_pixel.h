@@ -138,7 +138,7 @@ struct Px {
     float cur_n;                 /* Ray::current_refractive_index src/ray.cu:56,144 */
     float best_t;
     int best_obj, best_prim, next_mesh;
-    /* bits 3..0: which frame of a multi-frame launch this pixel belongs to; bits 31..4: the traversal
+    /* bits RT_FRAME_BITS-1..0: which frame of a multi-frame launch this pixel belongs to; the bits above: the traversal
      * macro steps it has cost so far, reported per tile when the launch collects costs (tile_cost) */
     unsigned frame_steps;
 #ifdef RT_COSTMAP
@@ -212,11 +212,11 @@ __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, 
         /* (first launch of a view) what this pixel cost, charged to its tile */
         const int band = p.py / a.band_rows;
         const int tile = ((band - a.band_first) / a.band_stride) * f.tiles_per_band + ((p.py - band * a.band_rows) >> 3) * a.tiles_x + (p.px >> 3);
-        atomicAdd(a.tile_cost + tile, p.frame_steps >> 4);
+        atomicAdd(a.tile_cost + tile, p.frame_steps >> RT_FRAME_BITS);
     }
     p.mode = M_FETCH;
     if (a.partial) {
-        float *dst = a.partial + ((size_t)(p.frame_steps & 15u) * a.partial_plane + pixel) * 3;
+        float *dst = a.partial + ((size_t)(p.frame_steps & (unsigned)(RT_MAX_BATCH_FRAMES - 1)) * a.partial_plane + pixel) * 3;
         dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
         return;
     }

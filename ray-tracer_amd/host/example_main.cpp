@@ -4,7 +4,10 @@
  * progressive frames, write the float->RGBA8 result (src/main.cu:343-371) as a binary PPM or,
  * if the name ends in .png, as a PNG like the reference's images/ directory.
  *
- *   example_main <models_dir> <scene 0..3> <width> <height> <frames> <out.ppm|out.png>
+ *   example_main <models_dir> <scene 0..3> <width> <height> <frames> <out.ppm|out.png> [devices, e.g. 0,1,2,3]
+ *
+ * With a device list the same loop runs on a MultiRenderer: every listed GPU renders the bands it owns,
+ * the image is the same (a device may be listed twice to rehearse on a one-GPU machine).
  *
  * Build:  g++ -std=c++17 -O2 example_main.cpp -L.. -lraytracer_amd -Wl,-rpath,'$ORIGIN/..'
  */
@@ -20,7 +23,7 @@ using namespace rtamd;
 int main(int argc, char **argv)
 {
     if (argc < 7) {
-        std::fprintf(stderr, "usage: %s <models_dir> <scene 0..3> <width> <height> <frames> <out.ppm|out.png>\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <models_dir> <scene 0..3> <width> <height> <frames> <out.ppm|out.png> [devices]\n", argv[0]);
         return 2;
     }
     const std::string models = argv[1];
@@ -29,17 +32,28 @@ int main(int argc, char **argv)
         SceneObjects mesh_data(scene_num, models);                 /* init(): src/main.cu:389-398 */
         RenderData render_data(100, 5, true, mesh_data.use_sky ? Vec3(0.8f, 1, 1) : Vec3(0, 0, 0));
         Camera camera(W, H);
-        Renderer renderer(0);
-        renderer.set_scene(mesh_data);
         VariableRenderData data{0, std::vector<float>((size_t)W * (size_t)H * 3, 0.0f)};
-        /* the first frame as the reference does it, one render() per frame ... */
-        renderer.render(camera, render_data, &data, 12345);          /* get_time() in the reference */
-        std::printf("frame %d: %.2f ms\n", data.frame_num, renderer.last_kernel_ms());
-        /* ... the others in one call: the same image, frames overlapping on the GPU */
         std::vector<int> times;
         for (int f = 1; f < frames; f++) times.push_back(12345 + f);
-        renderer.render_frames(camera, render_data, &data, times);
-        if (!times.empty()) std::printf("frames 2..%d: %.2f ms\n", data.frame_num, renderer.last_kernel_ms());
+        if (argc > 7) {
+            std::vector<int> devices;
+            for (const char *p = argv[7]; *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; }
+            MultiRenderer renderer(devices);
+            renderer.set_scene(mesh_data);
+            renderer.render(camera, render_data, &data, 12345);
+            std::printf("frame %d on %d GPUs: %.2f ms\n", data.frame_num, renderer.num_gpus(), renderer.last_kernel_ms());
+            renderer.render_frames(camera, render_data, &data, times);
+            if (!times.empty()) std::printf("frames 2..%d: %.2f ms\n", data.frame_num, renderer.last_kernel_ms());
+        } else {
+            Renderer renderer(0);
+            renderer.set_scene(mesh_data);
+            /* the first frame as the reference does it, one render() per frame ... */
+            renderer.render(camera, render_data, &data, 12345);          /* get_time() in the reference */
+            std::printf("frame %d: %.2f ms\n", data.frame_num, renderer.last_kernel_ms());
+            /* ... the others in one call: the same image, frames overlapping on the GPU */
+            renderer.render_frames(camera, render_data, &data, times);
+            if (!times.empty()) std::printf("frames 2..%d: %.2f ms\n", data.frame_num, renderer.last_kernel_ms());
+        }
         std::vector<uint8_t> rgba = parse_pixel_colours(data.previous_render, W, H);
         const std::string out = argv[6];
         if (out.size() > 4 && out.compare(out.size() - 4, 4, ".png") == 0) {

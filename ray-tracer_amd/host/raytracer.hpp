@@ -367,6 +367,87 @@ private:
     }
 };
 
+/* Several GPUs of one node behind the same render() (rt_render_multi): device i of `devices` renders the
+ * 8-row bands b with b % n == i, the bands meet on devices[0].  The image is the single-GPU image bit for
+ * bit (a pixel depends only on its coordinates, its seed and its previous value, src/raytracer.cu:118-131).
+ * The reference is single-GPU; this is what its main loop calls when the node has more than one. */
+class MultiRenderer {
+public:
+    explicit MultiRenderer(const std::vector<int> &devices)
+    {
+        if (devices.empty()) throw std::invalid_argument("no devices");
+        for (int d : devices) {
+            rt_ctx *c = nullptr;
+            rt_status st = rt_ctx_create(d, &c);
+            if (st != RT_OK) {
+                release();
+                if (st == RT_ERR_NO_DEVICE) throw std::runtime_error("Error from HIP (creating context): no usable GPU; there is no CPU fallback");
+                throw std::runtime_error("Error from HIP (creating context): status " + std::to_string(st));
+            }
+            ranks_.push_back(rt_rank{c, nullptr});
+        }
+    }
+    ~MultiRenderer() { release(); }
+    MultiRenderer(const MultiRenderer &) = delete;
+    MultiRenderer &operator=(const MultiRenderer &) = delete;
+
+    int num_gpus() const { return (int)ranks_.size(); }
+    /* every GPU holds the whole scene (it is tens of KB) */
+    void set_scene(const SceneObjects &objs)
+    {
+        for (rt_rank &r : ranks_) {
+            rt_scene_destroy(const_cast<rt_scene *>(r.scene));
+            r.scene = nullptr;
+            rt_scene *s = nullptr;
+            check(r.ctx, rt_scene_commit(r.ctx, objs.handle(), &s));
+            r.scene = s;
+        }
+    }
+    /* render(VariableRenderData*, int) src/dispatch.cu:156-163 */
+    void render(const Camera &cam, const RenderData &rd, VariableRenderData *data, int current_time_ms)
+    {
+        render_frames(cam, rd, data, std::vector<int>{current_time_ms});
+    }
+    void render_frames(const Camera &cam, const RenderData &rd, VariableRenderData *data, const std::vector<int> &times_ms)
+    {
+        if (data->previous_render.size() != (size_t)cam.c.width * (size_t)cam.c.height * 3) throw std::invalid_argument("previous_render has the wrong size");
+        if (times_ms.empty()) return;
+        std::vector<int32_t> t(times_ms.begin(), times_ms.end());
+        int32_t fn = data->frame_num;
+        check(ranks_[0].ctx, rt_render_multi(ranks_.data(), (int32_t)ranks_.size(), &cam.c, &rd.c, t.data(), (int32_t)t.size(), &fn, data->previous_render.data()));
+        data->frame_num = fn;
+    }
+    /* the slowest rank's kernel time of the last call */
+    float last_kernel_ms()
+    {
+        float worst = 0;
+        for (rt_rank &r : ranks_) {
+            float ms = 0;
+            if (rt_last_kernel_ms(r.ctx, &ms) == RT_OK && ms > worst) worst = ms;
+        }
+        return worst;
+    }
+
+private:
+    std::vector<rt_rank> ranks_;
+    void release()
+    {
+        for (rt_rank &r : ranks_) {
+            rt_scene_destroy(const_cast<rt_scene *>(r.scene));
+            rt_ctx_destroy(r.ctx);
+        }
+        ranks_.clear();
+    }
+    static void check(rt_ctx *ctx, rt_status st)
+    {
+        if (st == RT_OK) return;
+        std::string msg = rt_last_error(ctx);
+        if (st == RT_ERR_UNSUPPORTED) throw std::logic_error(msg);
+        if (st == RT_ERR_INVALID) throw std::invalid_argument(msg);
+        throw std::runtime_error(msg);
+    }
+};
+
 /* parse_pixel_colours src/main.cu:343-371: int(px*255), clamp, alpha 255 */
 inline std::vector<uint8_t> parse_pixel_colours(const std::vector<float> &pixel_colours, int width, int height)
 {

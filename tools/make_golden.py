@@ -53,6 +53,16 @@ np.save(os.path.join(GOLD, "fb_three_sphere_96x64_progressive.npy"), np.stack([f
 # cameras
 meta["camera_det"] = {"%dx%d" % (w, h): [float(x) for x in B.camera_default(w, h, B.MATH_DET)] for w, h in ((256, 256), (1920, 1080), (3840, 2160))}
 
+# The reference's own camera floats (libm mode = the glibc 2.35 tanf the survey's CPU build of the reference used;
+# the values are SURVEY.md App. A.12's, tests/test_oracle_pin.py checks them) as DATA: passed verbatim through
+# rt_camera they make the HIP kernel reproduce the reference outputs the survey recorded (App. C.2) - the math
+# binding (rt_math.h vs glibc) flips no decision in those frames, the 1-ulp tanf of the camera does.
+meta["camera_libm"] = {"%dx%d" % (w, h): [float(x) for x in B.camera_default(w, h, B.MATH_LIBM)] for w, h in ((256, 256), (1920, 1080), (3840, 2160))}
+meta["reference_recorded_256x256_s16"] = {"three_sphere": {"limit": 4, "sha256_prefix": "479589c110c5b34e", "mean": 0.472370008},
+                                          "cube": {"limit": 8, "sha256_prefix": "b4dcdd058b1bc676", "mean": 0.650935728},
+                                          "monkey": {"limit": 8, "sha256_prefix": "24682f69ae058766", "mean": 0.19924736, "max": 7.828125},
+                                          "source": "SURVEY.md App. C.2 (outputs of the reference's sources compiled CPU-only by the survey session)"}
+
 # transformed monkey triangles (det-mode sin/cos), 723 x 9
 ob = B.Obj(os.path.join(md, "low_poly_monkey.obj"), B.MATH_DET)
 ob.enlarge(0.3); ob.rotate(0, 2.3, 0); ob.translate(0.1, -0.1, 1.6)

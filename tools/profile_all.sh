@@ -1,26 +1,35 @@
 #!/bin/bash
-# rocprofv3 passes for the render kernel at the bench configuration (run on the GPU box from the
-# repo root).  usage: tools/profile_all.sh <tag>
-#   pass 0: --kernel-trace --stats on the default bench.py workload (8 frames per launch; warm-up of the
-#           same size and no extra legs, so that every launch of the kernel is of the kind that is timed)
-#   pass 1-3: SQ counters, pass 4/5: FETCH_SIZE / WRITE_SIZE, each in its own run (PMC and
-#   tracing are never combined), on one launch of the same workload (tools/profile_run.py: the
-#   8-frame launch of the default bench).
+# rocprofv3 passes for the render kernel at the bench configurations (run on the GPU box from the repo
+# root).  usage: tools/profile_all.sh <tag> [scenes...]     (default scenes: monkey three_sphere cube)
+#   per scene (BASELINE configs[3], [1], [2]; 1920x1080, 1024 spp, 8 bounces):
+#     stats:   --kernel-trace --stats on bench.py in the DRIVER's shape (--steps 20 --warmup 5, no extra legs:
+#              every launch of the kernel is then of the kind that is timed)
+#     pmc1-3:  SQ counters on one 8-frame launch (tools/profile_run.py; a 1-spp warm-up launch comes first)
+#     hbm:     FETCH_SIZE / WRITE_SIZE, each in its own run, on launches of 1, 8 and 20 frames -> traffic.json
+#   PMC and tracing are never combined in one run; the program comes directly after `--`.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}; shift
+SCENES=${@:-monkey three_sphere cube}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 8 --warmup 8 --no-cpu-baseline --no-frame-by-frame-leg > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-echo "stats pass exit=$?"
-i=0
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
-           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD" \
-           "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" \
-           "FETCH_SIZE" "WRITE_SIZE"; do
-  i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/pmc$i -- python3 tools/profile_run.py monkey 1024 1920 1080 8 > $OUT/pmc$i.log 2> $OUT/pmc$i.err
-  echo "pmc pass $i ($set) exit=$?"
+declare -A CFG=([monkey]=3 [three_sphere]=1 [cube]=2)
+for s in $SCENES; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$s -- python3 bench.py --config ${CFG[$s]} --steps 20 --warmup 5 --no-cpu-baseline --no-frame-by-frame-leg > $OUT/bench_under_rocprof_$s.json 2> $OUT/stats_$s.err
+  echo "$s stats pass exit=$?"
+  i=0
+  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SALU" \
+             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD" \
+             "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU"; do
+    i=$((i+1))
+    rocprofv3 --pmc $set --output-format csv -d $OUT/pmc${i}_$s -- python3 tools/profile_run.py $s 1024 1920 1080 8 > $OUT/pmc${i}_$s.log 2> $OUT/pmc${i}_$s.err
+    echo "$s pmc pass $i exit=$?"
+  done
+  for f in 1 8 20; do
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/hbm_${s}_f${f}_fetch -- python3 tools/profile_run.py $s 1024 1920 1080 $f > $OUT/hbm_${s}_f${f}_fetch.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/hbm_${s}_f${f}_write -- python3 tools/profile_run.py $s 1024 1920 1080 $f > $OUT/hbm_${s}_f${f}_write.log 2>&1
+    echo "$s hbm passes f=$f exit=$?"
+  done
 done
-python3 tools/summarize_profile.py $OUT > $OUT/summary.txt
+python3 tools/summarize_profile.py $OUT $SCENES > $OUT/summary.txt
 cat $OUT/summary.txt
