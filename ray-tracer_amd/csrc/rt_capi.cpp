@@ -62,6 +62,14 @@ struct rt_ctx {
     int cost_state = 0;                  /* 0 nothing, 1 the last launch with this key collected costs, 2 the order has been refined with them */
     int order_num_heavy = 0;             /* refined order: how many leading tiles go first for ALL frames of a multi-frame launch */
     int heavy_top = 1024;                /* RT_AMD_HEAVY_TOP: that many at most (0 = never refine) */
+    /* multi-frame launches, once the tile costs of the view are known: the whole schedule (ticket -> tile, frame),
+     * longest job first over all frames (see build_job_order) */
+    std::vector<uint32_t> cost_host;     /* the measured costs (per tile of the launch) */
+    uint32_t *d_job_order = nullptr;
+    size_t job_cap = 0;
+    int job_frames = 0;                  /* what the uploaded schedule was built for (with order_key) */
+    int lpt = 1;                         /* RT_AMD_LPT=0: the round-1 ticket order (heavy tiles of frame 0, 1, ... first) */
+    int lpt_top = 1 << 30;               /* RT_AMD_LPT_TOP: at most this many tiles (most expensive first) are scheduled by cost */
     int heavy_first = 1;                 /* RT_AMD_HEAVY_FIRST=0 disables */
     int work_threshold = 8;      /* lanes; RT_AMD_WORK_THRESHOLD overrides (tuning: tools/ab_threshold.py) */
     int descend_keep = 24;       /* RT_AMD_DESCEND_KEEP (0..64): 0 = run every descent to its end */
@@ -143,6 +151,8 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (const char *e = getenv("RT_AMD_TILE_SCATTER")) ctx->tile_scatter = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_HEAVY_FIRST")) ctx->heavy_first = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_HEAVY_TOP")) { int v = atoi(e); if (v >= 0) ctx->heavy_top = v; }
+    if (const char *e = getenv("RT_AMD_LPT")) ctx->lpt = atoi(e) != 0;
+    if (const char *e = getenv("RT_AMD_LPT_TOP")) { int v = atoi(e); if (v >= 0) ctx->lpt_top = v; }
     if (const char *e = getenv("RT_AMD_HIT_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->hit_break = v; }
     if (const char *e = getenv("RT_AMD_SHADE_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->shade_batch = v; }
     if (const char *e = getenv("RT_AMD_POOL")) ctx->use_pool = atoi(e) != 0;
@@ -168,6 +178,7 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
     if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
+    if (ctx->d_job_order) (void)hipFree(ctx->d_job_order);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
     if (ctx->d_bands) (void)hipFree(ctx->d_bands);
     if (ctx->d_stage) (void)hipFree(ctx->d_stage);
@@ -289,6 +300,42 @@ extern "C" int32_t rt_tile_owned_rows(const rt_tile_spec *t, int32_t height)
     return owned * t->band_rows;
 }
 
+/* persistent waves: enough workgroups to fill the chip, each wave pulls 8x8 tiles */
+static int launch_blocks(const rt_ctx *ctx, const rt_scene *scene, int num_tiles)
+{
+    const int waves_per_block = scene->threads / 64;
+    int blocks_per_cu = scene->flat.has_mesh ? 1 : 4;
+    if (!scene->flat.has_mesh && scene->lds_bytes > 0) {
+        int by_lds = (int)(RT_LDS_LIMIT / scene->lds_bytes);
+        if (by_lds < blocks_per_cu) blocks_per_cu = by_lds < 1 ? 1 : by_lds;
+    }
+    int blocks = ctx->num_cus * blocks_per_cu;
+    const int needed = (num_tiles + waves_per_block - 1) / waves_per_block;
+    return blocks > needed ? needed : blocks;
+}
+
+/* the schedule of a multi-frame launch (see its use in render_frames): `order` is the launch's tile order
+ * (any permutation of 0..n-1; ties in cost keep it), cost[t] the measured cost of tile t */
+static void build_job_order(const std::vector<uint32_t> &order, const std::vector<uint32_t> &cost, uint32_t top_max, uint32_t frames,
+                            std::vector<uint32_t> &jobs)
+{
+    const uint32_t n = (uint32_t)order.size();
+    std::vector<uint32_t> idx(order);
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+    uint32_t top = top_max < n ? top_max : n;
+    while (top > 0 && cost[idx[top - 1]] == 0) top--;
+    jobs.clear();
+    jobs.reserve((size_t)n * frames);
+    /* by decreasing cost, the frames of a tile together */
+    for (uint32_t r = 0; r < top; r++)
+        for (uint32_t f = 0; f < frames; f++) jobs.push_back(idx[r] | (f << RT_JOB_FRAME_SHIFT));
+    /* everything else frame by frame, in the launch's tile order */
+    std::vector<char> taken(n, 0);
+    for (uint32_t r = 0; r < top; r++) taken[idx[r]] = 1;
+    for (uint32_t f = 0; f < frames; f++)
+        for (uint32_t t : order) if (!taken[t]) jobs.push_back(t | (f << RT_JOB_FRAME_SHIFT));
+}
+
 /* one launch rendering n_frames consecutive progressive frames (n_frames == 1: a plain frame with an
  * optional separate previous frame; > 1: d_out is updated in place) */
 static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
@@ -297,7 +344,8 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
 {
     if (!ctx || !scene || !cam || !rs || !d_out) return set_err(ctx, RT_ERR_INVALID, "null argument");
     if (scene->ctx != ctx) return set_err(ctx, RT_ERR_INVALID, "scene belongs to another context");
-    if (cam->width <= 0 || cam->height <= 0 || (int64_t)cam->width * cam->height > (1 << 28)) return set_err(ctx, RT_ERR_INVALID, "bad image size");
+    if (cam->width <= 0 || cam->height <= 0 || cam->width > 32768 || cam->height > 32768 || (int64_t)cam->width * cam->height > (1 << 28))
+        return set_err(ctx, RT_ERR_INVALID, "bad image size (at most 32768 pixels on a side and 2^28 in all)");
     if (rs->rays_per_pixel < 0 || rs->reflection_limit < 0) return set_err(ctx, RT_ERR_INVALID, "bad render settings");
     rt_tile_spec full = {8, 0, 1, 0};
     const rt_tile_spec *t = tiles ? tiles : &full;
@@ -400,6 +448,7 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
                 ctx->order_host.swap(order);
                 ctx->order_num_heavy = 0;
                 ctx->cost_state = 0;
+                ctx->job_frames = 0;
             }
             /* The guess above is refined once per view with what the tiles really cost: the first
              * launch of a view also adds up, per tile, the traversal steps of its pixels; the second
@@ -434,9 +483,38 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
                 ctx->order_host.swap(merged);
                 ctx->order_num_heavy = (int)top;
                 ctx->cost_state = 2;
+                ctx->cost_host.swap(cost);
+                ctx->job_frames = 0;                    /* any uploaded schedule is for another view */
             }
             a.num_heavy_tiles = (ctx->cost_state == 2 && n_frames > 1) ? ctx->order_num_heavy : 0;
             a.tile_order = ctx->d_tile_order;
+            /* Multi-frame launch of a view whose tile costs are known: the host lays out the whole schedule.
+             * A job is one tile of one frame; a pixel's samples are one sequential random stream, so a job
+             * cannot be split and the launch is at least as long as its longest job - which therefore has to
+             * start at once, for EVERY frame (frames only meet in the blend behind the kernel).  Longest
+             * processing time first: jobs in order of decreasing measured tile cost, all frames of a tile
+             * together; tiles that cost nothing (no ray enters a mesh) follow frame by frame.  Consecutive
+             * tickets are also similar in cost, so the lanes a wave refills as its cheap pixels finish
+             * collect pixels of one kind.  Any schedule renders the same image.  (Measured, 20 frames of the
+             * monkey configuration: +6 % on one GPU and +25 % on the share one of 8 GPUs renders, against
+             * "the 1,024 most expensive tiles of frame 0, of frame 1, ... first"; dealing the first round out
+             * so that a workgroup's 16 waves get 16 different cost strata changed nothing.) */
+            if (ctx->lpt && ctx->cost_state == 2 && n_frames > 1 && n <= (RT_JOB_TILE_MASK + 1u) && ctx->cost_host.size() == n) {
+                if (ctx->job_frames != n_frames) {
+                    std::vector<uint32_t> jobs;
+                    build_job_order(ctx->order_host, ctx->cost_host, (uint32_t)ctx->lpt_top, (uint32_t)n_frames, jobs);
+                    if (ctx->job_cap < jobs.size()) {
+                        if (ctx->d_job_order) (void)hipFree(ctx->d_job_order);
+                        ctx->d_job_order = nullptr; ctx->job_cap = 0;
+                        RT_HIP(ctx, hipMalloc((void **)&ctx->d_job_order, jobs.size() * 4), "allocating the launch schedule");
+                        ctx->job_cap = jobs.size();
+                    }
+                    RT_HIP(ctx, hipMemcpyAsync(ctx->d_job_order, jobs.data(), jobs.size() * 4, hipMemcpyHostToDevice, stream), "uploading the launch schedule");
+                    RT_HIP(ctx, hipStreamSynchronize(stream), "uploading the launch schedule");     /* `jobs` is a local */
+                    ctx->job_frames = n_frames;
+                }
+                a.job_order = ctx->d_job_order;
+            }
         }
     }
     a.objects = scene->d_objects;
@@ -482,16 +560,7 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
     RT_HIP(ctx, hipEventRecord(ctx->ev_start, stream), "recording start event");
     ctx->have_timing = false;
     if (a.num_tiles > 0) {
-        /* persistent waves: enough workgroups to fill the chip, each wave pulls 8x8 tiles */
-        const int waves_per_block = scene->threads / 64;
-        int blocks_per_cu = scene->flat.has_mesh ? 1 : 4;
-        if (!scene->flat.has_mesh && scene->lds_bytes > 0) {
-            int by_lds = (int)(RT_LDS_LIMIT / scene->lds_bytes);
-            if (by_lds < blocks_per_cu) blocks_per_cu = by_lds < 1 ? 1 : by_lds;
-        }
-        int blocks = ctx->num_cus * blocks_per_cu;
-        int needed = (a.num_tiles + waves_per_block - 1) / waves_per_block;
-        if (blocks > needed) blocks = needed;
+        const int blocks = launch_blocks(ctx, scene, a.num_tiles);
         RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 512, stream), "clearing tile counter");
         if (scene->pool)
             RT_HIP(ctx, rt_launch_render_pool(&a, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");

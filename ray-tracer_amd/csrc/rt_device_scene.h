@@ -32,6 +32,8 @@
 #define RT_STACK_ENTRIES RT_BVH_DEPTH /* at most one pending sibling per level below the root */
 #define RT_FRAME_BITS 5               /* a pixel keeps the index of its frame within the launch in this many bits */
 #define RT_MAX_BATCH_FRAMES (1 << RT_FRAME_BITS)   /* frames one launch can render */
+#define RT_JOB_FRAME_SHIFT 22          /* a job = tile | frame << 22 (2^28 pixels are 2^22 tiles) */
+#define RT_JOB_TILE_MASK 0x003fffffu
 #define RT_INF_F 1073741824.0f       /* reference `1 << 31 - 1` == 1 << 30, src/objects.cu:6 */
 #define RT_EPS_F 0.000001f           /* FLOAT_PRECISION_ERROR src/objects.cu:7 */
 
@@ -109,6 +111,8 @@ typedef struct {
     uint32_t tile_stride;          /* ticket t renders tile (t * tile_stride) % num_tiles; coprime to num_tiles */
     const uint32_t *tile_order;    /* or, if not NULL, tile tile_order[t] (expensive-looking tiles first) */
     int32_t num_heavy_tiles;       /* multi-frame launches: this many leading entries of tile_order go first for ALL frames */
+    const uint32_t *job_order;     /* or, if not NULL, the whole schedule of a multi-frame launch: ticket t renders tile
+                                      (job_order[t] & RT_JOB_TILE_MASK) of frame (job_order[t] >> RT_JOB_FRAME_SHIFT) */
     /* scene */
     const rt_object *objects;
     int32_t num_objects;

@@ -88,8 +88,12 @@ enum { ST_ITER = 0, ST_SHADE = 1, ST_SHADE_HIT = 2, ST_FETCH = 3, ST_GEN = 4, ST
 /* SCENE_LDS = false is the fallback for scenes larger than a CU's LDS: the same code reads the
  * scene sections from global memory (they stay L2 / Infinity-Cache resident) and only the
  * traversal stack lives in LDS. */
+/* Occupancy the launcher relies on (rt_capi.cpp): a mesh scene runs one workgroup per CU (NT = 1024: four
+ * waves per SIMD, which NT alone tells the compiler), a scene without a mesh four 256-thread workgroups per CU -
+ * also four waves per SIMD, which needs the second launch bound: without it the register allocator stops at
+ * 129 VGPRs, one over the 128 that four waves per SIMD leave each. */
 template <int NT, bool HAS_MESH, bool SCENE_LDS>
-__global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
+__global__ __launch_bounds__(NT, HAS_MESH ? 1 : 4) void rt_render_kernel(const rt_kernel_args a)
 {
     extern __shared__ v4f lds_raw[];
     const int tid = threadIdx.x;
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
     px_init(p);
     /* ---- per-lane traversal state (registers + LDS stack); a lane is traversing iff M_WAIT ---- */
     uint32_t cur = 0;
-    int sp = 0, w_prim = -1, w_obj = -1;
+    int sp = 0, w_prim = -1;
     float w_best = RT_INF_F;
     Chunk ch;
     ch.next = 0; ch.end = 0; ch.frame = 0; ch.exhausted = false;
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                 float rd;
                 const bool rh = box_test(m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, p.o, p.inv, rd);
                 if (!rh || rd > RT_INF_F || ((root_ref & RT_REF_CHAIN) && !(rd < RT_INF_F))) continue;
-                cur = root_ref; sp = 0; w_best = RT_INF_F; w_prim = -1; w_obj = (int)__float_as_uint(m1.w);
+                cur = root_ref; sp = 0; w_best = RT_INF_F; w_prim = -1;
                 p.mode = M_WAIT;
                 RT_STAT(ST_MESH_START);
             }
@@ -275,7 +279,9 @@ __global__ __launch_bounds__(NT) void rt_render_kernel(const rt_kernel_args a)
                             cur = take ? e.y : RT_REF_EMPTY_LEAF;
                         } else {
                             RT_STAT(ST_DONE_MESH);
-                            /* this mesh is done: merge (smaller distance, or equal and later in the list) */
+                            /* this mesh is done: merge (smaller distance, or equal and later in the list);
+                             * its place in the object list is read again here rather than kept in a register */
+                            const int w_obj = (int)__float_as_uint(L.meshes[2 * (p.next_mesh - 1) + 1].w);
                             if (w_prim >= 0 && (w_best < p.best_t || (w_best == p.best_t && w_obj > p.best_obj))) {
                                 p.best_t = w_best; p.best_obj = w_obj; p.best_prim = w_prim;
                             }

@@ -134,7 +134,8 @@ struct Px {
     int mode;
     uint32_t rng;
     V3 colour, fin, thr, o, d, inv, primary;
-    int sample, bounce, px, py;
+    int sample, bounce;
+    unsigned pxy;                /* the pixel: y << 16 | x (images are at most 32,768 pixels on a side) */
     float cur_n;                 /* Ray::current_refractive_index src/ray.cu:56,144 */
     float best_t;
     int best_obj, best_prim, next_mesh;
@@ -171,7 +172,7 @@ __device__ __forceinline__ void px_init(Px &p)
     const V3 z = v3(0.f, 0.f, 0.f);
     p.mode = M_FETCH; p.rng = 0;
     p.colour = z; p.fin = z; p.thr = z; p.o = z; p.d = z; p.inv = z; p.primary = z;
-    p.sample = 0; p.bounce = 0; p.px = 0; p.py = 0;
+    p.sample = 0; p.bounce = 0; p.pxy = 0;
     p.cur_n = 1.0f; p.best_t = RT_INF_F;
     p.best_obj = -1; p.best_prim = -1; p.next_mesh = 0; p.frame_steps = 0;
     RT_COST(p.c_steps = 0; p.c_t0 = 0; p.c_wsteps = 0);
@@ -202,16 +203,17 @@ __device__ __forceinline__ void frame_init(Frame &f, const rt_kernel_args &a)
 __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, const Frame &f)
 {
     const V3 c = p.colour / (float)f.spp;
-    int out_row = p.py;
+    const int px = (int)(p.pxy & 0xffffu), py = (int)(p.pxy >> 16);
+    int out_row = py;
     if (a.compact) {
-        const int band = p.py / a.band_rows;
-        out_row = ((band - a.band_first) / a.band_stride) * a.band_rows + (p.py - band * a.band_rows);
+        const int band = py / a.band_rows;
+        out_row = ((band - a.band_first) / a.band_stride) * a.band_rows + (py - band * a.band_rows);
     }
-    const size_t pixel = (size_t)out_row * (size_t)f.W + (size_t)p.px;
+    const size_t pixel = (size_t)out_row * (size_t)f.W + (size_t)px;
     if (a.tile_cost) {
         /* (first launch of a view) what this pixel cost, charged to its tile */
-        const int band = p.py / a.band_rows;
-        const int tile = ((band - a.band_first) / a.band_stride) * f.tiles_per_band + ((p.py - band * a.band_rows) >> 3) * a.tiles_x + (p.px >> 3);
+        const int band = py / a.band_rows;
+        const int tile = ((band - a.band_first) / a.band_stride) * f.tiles_per_band + ((py - band * a.band_rows) >> 3) * a.tiles_x + (px >> 3);
         atomicAdd(a.tile_cost + tile, p.frame_steps >> RT_FRAME_BITS);
     }
     p.mode = M_FETCH;
@@ -221,7 +223,7 @@ __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, 
         return;
     }
     float *dst = a.out + pixel * 3;
-    const int array_index = (p.py * f.W + p.px) * 3;
+    const int array_index = (py * f.W + px) * 3;
     V3 previous = v3(0.f, 0.f, 0.f);
     if (a.prev) previous = v3(a.prev[array_index], a.prev[array_index + 1], a.prev[array_index + 2]);
     V3 previous_sum = previous * (float)a.frame_num;
@@ -400,6 +402,15 @@ __device__ __forceinline__ void px_fetch(Px &p, Chunk &ch, const rt_kernel_args 
          * long as its work, not as its last frame's tail.  (num_heavy_tiles == 0, or one frame:
          * plainly frame by frame.) */
         if (t >= (uint32_t)a.num_tiles * (uint32_t)a.num_frames) { ch.exhausted = true; break; }
+        if (a.job_order) {
+            /* the host has laid out the whole schedule (rt_capi.cpp: longest job first over all frames) */
+            const uint32_t job = a.job_order[t];
+            ch.frame = (int)(job >> RT_JOB_FRAME_SHIFT);
+            t = job & RT_JOB_TILE_MASK;
+            ch.next = t * 64u;
+            ch.end = t * 64u + 64u;
+            continue;
+        }
         uint32_t fr;
         const uint32_t nh = (uint32_t)a.num_heavy_tiles;
         if (t < nh * (uint32_t)a.num_frames) {
@@ -429,16 +440,17 @@ __device__ __forceinline__ void px_fetch(Px &p, Chunk &ch, const rt_kernel_args 
     const int in_band = tile - band_local * f.tiles_per_band;
     const int band = a.band_first + band_local * a.band_stride;
     const int ty = in_band / a.tiles_x, tx = in_band - ty * a.tiles_x;
-    p.px = tx * 8 + (within & 7);
-    p.py = band * a.band_rows + ty * 8 + (within >> 3);
-    if (p.px < f.W && p.py < f.H) {
+    const int px = tx * 8 + (within & 7);
+    const int py = band * a.band_rows + ty * 8 + (within >> 3);
+    p.pxy = ((unsigned)py << 16) | (unsigned)px;
+    if (px < f.W && py < f.H) {
         /* src/raytracer.cu:123-127; Ray::set_direction_origin src/ray.cu:147-155,
          * cam_pixel_to_world src/camera.cu:24-29 */
-        const int array_index = (p.py * f.W + p.px) * 3;
+        const int array_index = (py * f.W + px) * 3;
         p.frame_steps = (unsigned)my_frame;
         p.rng = (uint32_t)array_index * 3145739u + a.seeds[my_frame];
         RT_COST(p.c_steps = 0; p.c_wsteps = 0; p.c_t0 = (unsigned)wall_clock64());
-        V3 plane_point = f.du * (float)p.px + f.dv * (float)p.py;
+        V3 plane_point = f.du * (float)px + f.dv * (float)py;
         p.primary = normalised((f.tl + plane_point) - f.cam_pos);
         p.colour = v3(0.f, 0.f, 0.f);
         p.fin = v3(0.f, 0.f, 0.f); p.thr = v3(1.f, 1.f, 1.f);

@@ -560,5 +560,14 @@ def test_batch_entry_one_frame_at_a_time(rt, ctx):
         a, b = b, a
         rt.render_device_batch(ctx, scene, cam, rd, [70 + i], i, fr.data_ptr(), stream=st)
         assert torch.equal(fr.view(torch.int32), a.view(torch.int32)), i
-    with pytest.raises(ValueError, match="1..16"):
-        rt.render_device_batch(ctx, scene, cam, rd, list(range(17)), 0, fr.data_ptr(), stream=st)     # more than 16 frames per launch
+    with pytest.raises(ValueError, match="1..32"):
+        rt.render_device_batch(ctx, scene, cam, rd, list(range(33)), 0, fr.data_ptr(), stream=st)     # more than 32 frames per launch
+    # 32 frames in one launch (the frame index of a pixel uses all its bits) against 32 launches
+    times = list(range(900, 932))
+    x = torch.zeros((H, W, 3), device="cuda:0"); y = torch.empty_like(x)
+    for i, t in enumerate(times):
+        rt.render_device(ctx, scene, cam, rd, t, i, y.data_ptr(), d_prev=x.data_ptr() if i else None, stream=st)
+        x, y = y, x
+    rt.render_device_batch(ctx, scene, cam, rd, times, 0, fr.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert torch.equal(fr.view(torch.int32), x.view(torch.int32))

@@ -1,6 +1,7 @@
-"""What one rank of an N-GPU run does, measured on ONE GPU (development tool): renders the bands
-rank 0 would own for N = 1, 2, 4, 8 and prints the kernel time; T(1)/T(N) is the best-case
-strong-scaling speed-up (the gather adds ~0.1 ms)."""
+"""What the ranks of an N-GPU strong-scaling run do, measured on ONE GPU (development tool): for N = 1, 2, 4, 8
+renders, one rank after another, the bands each rank would own of `frames` progressive frames (one multi-frame
+launch per rank, as bench.py does) and prints the slowest rank's kernel time; T(1)/T(N) projects the strong-scaling
+speed-up (the gather adds ~0.1 ms per rank).  usage: scaling_probe.py [spp] [frames] [W] [H] [scene]"""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,20 +9,25 @@ sys.path.insert(0, ROOT)
 rt = importlib.import_module("ray-tracer_amd")
 dm = importlib.import_module("ray-tracer_amd.distributed")
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
-objs, sky = rt.scenes.monkey()
-ctx = rt.Context(0)
-scene = ctx.commit(rt.SceneObjects(objs))
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (1920, 1080)
+name = sys.argv[5] if len(sys.argv) > 5 else "monkey"
+objs, sky = rt.scenes.CONFIG_SCENES[name]()
 cam, rd = rt.Camera(W, H), rt.RenderData(spp, 8, True, sky)
+st = torch.cuda.current_stream().cuda_stream
 t1 = None
 for n in (1, 2, 4, 8):
-    worst = 0.0
-    for r in sorted(set((0, n // 2, n - 1))):
-        buf = torch.empty((dm.max_owned_rows(H, 8, n), W, 3), device="cuda:0")
-        ts = []
-        for _ in range(3):
-            rt.render_device(ctx, scene, cam, rd, 12345, 0, buf.data_ptr(), band_first=r, band_stride=n, compact=True, stream=torch.cuda.current_stream().cuda_stream)
-            ts.append(ctx.last_kernel_ms())
-        worst = max(worst, sorted(ts)[1])
+    per_rank = []
+    for r in range(n):
+        ctx = rt.Context(0)                      # a rank is a process with its own context: its own tile-order cache
+        scene = ctx.commit(rt.SceneObjects(objs))
+        buf = torch.zeros((dm.max_owned_rows(H, 8, n), W, 3), device="cuda:0")
+        # warm-up launch of 5 frames (collects tile costs, like bench.py --warmup 5), then the timed launch
+        rt.render_device_batch(ctx, scene, cam, rd, [12345 + i for i in range(min(5, frames))], 0, buf.data_ptr(), band_first=r, band_stride=n, compact=True, stream=st)
+        rt.render_device_batch(ctx, scene, cam, rd, [12345 + i for i in range(frames)], 0, buf.data_ptr(), band_first=r, band_stride=n, compact=True, stream=st)
+        per_rank.append(ctx.last_kernel_ms())
+        del scene, ctx
+    worst = max(per_rank)
     t1 = t1 or worst
-    print("N=%d: slowest rank %.1f ms  -> speed-up %.2fx (efficiency %.0f%%)" % (n, worst, t1 / worst, 100 * t1 / worst / n), flush=True)
+    print("N=%d: slowest rank %.1f ms (ranks: %s) -> %.0f Msamples/s, speed-up %.2fx (efficiency %.0f%%)" % (
+        n, worst, " ".join("%.0f" % v for v in per_rank), W * H * spp * frames / worst / 1e3, t1 / worst, 100 * t1 / worst / n), flush=True)
