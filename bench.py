@@ -328,7 +328,7 @@ def main():
                       "steps": ("consecutive progressive frames (seeds 12345 + i) in launches of up to %d frames per rank, gathered once" % MAX_BATCH) if batched
                                else "one launch + one gather per step",
                       "image": "%dx%d" % (W, H),
-                      "threads_per_block": info["threads_per_block"], "lds_bytes": info["lds_bytes"]},
+                      "threads_per_block": info["threads_per_block"], "blocks_per_cu": info["blocks_per_cu"], "lds_bytes": info["lds_bytes"]},
            "roofline": roofline}
     if ranks_info is not None:
         out["ranks"] = ranks_info

@@ -155,9 +155,10 @@ const char *rt_last_error(const rt_ctx *ctx);
  * flattens the builder's objects into the compact device layout and uploads it */
 rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_scene **out);
 void rt_scene_destroy(rt_scene *s);
-/* introspection for tests: bytes staged in LDS per workgroup, node / triangle counts */
+/* introspection for tests: bytes of LDS per workgroup, node / triangle counts, the launch shape chosen for the
+ * scene (workgroup size and how many workgroups are resident per CU) */
 typedef struct rt_scene_info {
-    int32_t num_objects, num_triangles, num_nodes, lds_bytes, scene_in_lds, threads_per_block, stack_entries;
+    int32_t num_objects, num_triangles, num_nodes, lds_bytes, scene_in_lds, threads_per_block, stack_entries, blocks_per_cu;
 } rt_scene_info;
 rt_status rt_scene_get_info(const rt_scene *s, rt_scene_info *out);
 

@@ -53,7 +53,7 @@ class rt_rank(C.Structure):
 
 
 class rt_scene_info(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("num_objects", "num_triangles", "num_nodes", "lds_bytes", "scene_in_lds", "threads_per_block", "stack_entries")]
+    _fields_ = [(n, C.c_int32) for n in ("num_objects", "num_triangles", "num_nodes", "lds_bytes", "scene_in_lds", "threads_per_block", "stack_entries", "blocks_per_cu")]
 
 
 class rt_flat_view(C.Structure):

@@ -14,7 +14,9 @@ LIB = os.path.join(HERE, "libraytracer_amd.so")
 SOURCES = [os.path.join(HERE, "csrc", f) for f in ("rt_kernel.hip", "rt_capi.cpp", "rt_host.cpp")]
 HEADERS = [os.path.join(HERE, "csrc", f) for f in ("rt_math.h", "rt_rng.h", "rt_device_scene.h", "rt_pixel.h", "rt_host.h")] + [
     os.path.join(ROOT, "include", "rt_amd.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
+# -fno-slp-vectorize: the SLP vectorizer pairs the scalar f32 adds / multiplies of the vector math into v_pk_*_f32, which
+# are not faster on gfx950 and need register pairs: 128 instead of ~90 VGPRs and ~10 % more time (same-box A/B, round 2).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17",
          "-Wall", "-Wno-unused-result", "-I" + os.path.join(ROOT, "include")]
 
 

@@ -32,6 +32,7 @@
 #define RT_STACK_ENTRIES RT_BVH_DEPTH /* at most one pending sibling per level below the root */
 #define RT_FRAME_BITS 5               /* a pixel keeps the index of its frame within the launch in this many bits */
 #define RT_MAX_BATCH_FRAMES (1 << RT_FRAME_BITS)   /* frames one launch can render */
+#define RT_SMALL_WG_WAVES 5            /* workgroups of fewer than 1024 threads are compiled for this many waves per SIMD (<= 96 VGPRs) */
 #define RT_JOB_FRAME_SHIFT 22          /* a job = tile | frame << 22 (2^28 pixels are 2^22 tiles) */
 #define RT_JOB_TILE_MASK 0x003fffffu
 #define RT_INF_F 1073741824.0f       /* reference `1 << 31 - 1` == 1 << 30, src/objects.cu:6 */

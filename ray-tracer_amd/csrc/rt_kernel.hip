@@ -88,12 +88,14 @@ enum { ST_ITER = 0, ST_SHADE = 1, ST_SHADE_HIT = 2, ST_FETCH = 3, ST_GEN = 4, ST
 /* SCENE_LDS = false is the fallback for scenes larger than a CU's LDS: the same code reads the
  * scene sections from global memory (they stay L2 / Infinity-Cache resident) and only the
  * traversal stack lives in LDS. */
-/* Occupancy the launcher relies on (rt_capi.cpp): a mesh scene runs one workgroup per CU (NT = 1024: four
- * waves per SIMD, which NT alone tells the compiler), a scene without a mesh four 256-thread workgroups per CU -
- * also four waves per SIMD, which needs the second launch bound: without it the register allocator stops at
- * 129 VGPRs, one over the 128 that four waves per SIMD leave each. */
+/* Occupancy.  Built with -fno-slp-vectorize the kernel needs ~90 VGPRs (the SLP vectorizer's packed-f32 pairs cost
+ * 128 and ~10 % of the time).  The 1024-thread workgroup of a large mesh scene is one per CU = four waves per SIMD,
+ * whatever the registers (its LDS holds the scene and 1024 traversal stacks); the smaller workgroups - scenes without a
+ * mesh, and mesh scenes small enough for several workgroups per CU - are register-bound, so they are compiled for
+ * five waves per SIMD (<= 96 VGPRs; the allocator then lands on 79-80, which lets six be resident).  The launcher
+ * asks the runtime how many workgroups of the chosen shape fit a CU (rt_kernel_blocks_per_cu). */
 template <int NT, bool HAS_MESH, bool SCENE_LDS>
-__global__ __launch_bounds__(NT, HAS_MESH ? 1 : 4) void rt_render_kernel(const rt_kernel_args a)
+__global__ __launch_bounds__(NT, NT == 1024 ? 4 : RT_SMALL_WG_WAVES) void rt_render_kernel(const rt_kernel_args a)
 {
     extern __shared__ v4f lds_raw[];
     const int tid = threadIdx.x;
@@ -754,6 +756,33 @@ extern "C" hipError_t rt_launch_eval(int op, const uint32_t *in, uint32_t *out, 
 }
 
 /* ---- launchers (called from rt_capi.cpp) -------------------------------------------------- */
+template <int NT, bool HAS_MESH, bool SCENE_LDS>
+static int rt_blocks_one(size_t lds_bytes)
+{
+    int n = 0;
+    (void)hipFuncSetAttribute((const void *)rt_render_kernel<NT, HAS_MESH, SCENE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)rt_render_kernel<NT, HAS_MESH, SCENE_LDS>, NT, lds_bytes) != hipSuccess) n = 0;
+    return n;
+}
+
+/* workgroups of this shape of rt_render_kernel that are resident on one CU (registers, LDS, wave slots), as the
+ * runtime reports it; 0 if the shape is not built */
+extern "C" int rt_kernel_blocks_per_cu(int has_mesh, int scene_in_lds, int threads, size_t lds_bytes)
+{
+    if (!scene_in_lds) {
+        if (has_mesh && threads == 1024) return rt_blocks_one<1024, true, false>(lds_bytes);
+        if (!has_mesh && threads == 256) return rt_blocks_one<256, false, false>(lds_bytes);
+        return 0;
+    }
+    switch (threads) {
+        case 256: return has_mesh ? rt_blocks_one<256, true, true>(lds_bytes) : rt_blocks_one<256, false, true>(lds_bytes);
+        case 512: return has_mesh ? rt_blocks_one<512, true, true>(lds_bytes) : rt_blocks_one<512, false, true>(lds_bytes);
+        case 768: return has_mesh ? rt_blocks_one<768, true, true>(lds_bytes) : rt_blocks_one<768, false, true>(lds_bytes);
+        case 1024: return has_mesh ? rt_blocks_one<1024, true, true>(lds_bytes) : rt_blocks_one<1024, false, true>(lds_bytes);
+        default: return 0;
+    }
+}
+
 template <int NT, bool HAS_MESH, bool SCENE_LDS>
 static void rt_launch_one(const rt_kernel_args *args, int blocks, size_t lds_bytes, hipStream_t stream)
 {

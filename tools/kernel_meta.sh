@@ -5,7 +5,7 @@
 set -e
 HERE=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$HERE/ray-tracer_amd/csrc/rt_kernel.hip
-FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -std=c++17 -I$HERE/include"
+FLAGS="--offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -std=c++17 -I$HERE/include"
 hipcc $FLAGS "$@" --cuda-device-only -c $SRC -o /tmp/rt_kernel.bundle 2>/dev/null
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --input=/tmp/rt_kernel.bundle --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --output=/tmp/rt_kernel.co
 hipcc $FLAGS "$@" --cuda-device-only -S $SRC -o /tmp/rt_kernel.s 2>/dev/null
