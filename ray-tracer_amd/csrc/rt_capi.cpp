@@ -76,7 +76,7 @@ struct rt_ctx {
     int work_threshold = 8;      /* lanes; RT_AMD_WORK_THRESHOLD overrides (tuning: tools/ab_threshold.py) */
     int descend_keep = 24;       /* RT_AMD_DESCEND_KEEP (0..64): 0 = run every descent to its end */
     int tile_scatter = 1;        /* RT_AMD_TILE_SCATTER=0: hand tiles out in raster order */
-    int ready_break = 24;        /* lanes; RT_AMD_READY_BREAK overrides; 65 = never */
+    int ready_break = 40;        /* lanes; RT_AMD_READY_BREAK overrides; 65 = never */
     int hit_break = 24;          /* lanes; RT_AMD_HIT_BREAK */
     int shade_batch = 40;        /* lanes; RT_AMD_SHADE_BATCH (1..64) */
     int use_pool = 0;            /* RT_AMD_POOL=1: mesh scenes through the workgroup ray pool (rt_render_pool_kernel); an experiment, slower */
