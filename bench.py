@@ -388,7 +388,10 @@ def measured_traffic(scene, W, H, spp, limit, my_pixels, frames, batched):
     share = my_pixels / float(W * H)
     if not batched:
         frames = 1
-    return e["fixed_bytes"] + frames * share * e["per_frame_bytes"], e.get("profile")
+    exact = e.get("points", {}).get(str(int(frames))) if float(frames).is_integer() else None
+    if exact is not None:          # this launch shape was profiled itself
+        return share * exact, e.get("profile")
+    return share * (e["fixed_bytes"] + frames * e["per_frame_bytes"]), e.get("profile")
 
 
 if __name__ == "__main__":

@@ -1,5 +1,5 @@
 """Fits profiles/traffic.json entries from the FETCH_SIZE / WRITE_SIZE passes of tools/profile_all.sh.
-usage: fit_traffic.py <prof dir> <tag>     (reads <prof dir>/hbm_<scene>_f<frames>_{fetch,write}/**/_counter_collection.csv)
+usage: fit_traffic.py <prof dir> <tag>     (reads <prof dir>/hbm_<scene>_<W>x<H>_s<spp>_f<frames>_{fetch,write}/**/_counter_collection.csv)
 
 One launch of f frames moves fixed + f * per_frame bytes; least squares over the measured f.  Units and the
 gfx950 correction as MI355X_MICROARCH.md's HBM section prescribes: FETCH_SIZE / WRITE_SIZE are KiB;
@@ -11,10 +11,10 @@ d, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pts = collections.defaultdict(lambda: collections.defaultdict(dict))      # scene -> frames -> {fetch, write}
 for sub in sorted(glob.glob(os.path.join(d, "hbm_*"))):
-    m = re.match(r"hbm_(\w+?)_f(\d+)_(fetch|write)$", os.path.basename(sub))
+    m = re.match(r"hbm_(\w+?)_(\d+x\d+_s\d+)_f(\d+)_(fetch|write)$", os.path.basename(sub))
     if not m:
         continue
-    scene, frames, kind = m.group(1), int(m.group(2)), m.group(3)
+    scene, frames, kind = m.group(1) + "_" + m.group(2) + "_l8", int(m.group(3)), m.group(4)
     total, last = collections.defaultdict(float), -1
     for f in glob.glob(os.path.join(sub, "**", "*_counter_collection.csv"), recursive=True):
         rows = [r for r in csv.DictReader(open(f)) if "rt_render_kernel" in r["Kernel_Name"]]
@@ -44,7 +44,7 @@ for scene, byf in pts.items():
         n = len(xs); mx = sum(xs) / n; my = sum(ys) / n
         per = sum((x - mx) * (y - my) for x, y in zip(xs, ys)) / sum((x - mx) ** 2 for x in xs)
         fixed = my - per * mx
-    key = "%s_1920x1080_s1024_l8" % scene
+    key = scene
     tj[key] = {"fixed_bytes": fixed, "per_frame_bytes": per, "points": {str(x): y for x, y in zip(xs, ys)},
                "fetch_write": {str(f): v for f, v in sorted(byf.items())}, "profile": "profiles/%s/" % tag}
     print(key, "fixed %.3f MB, per frame %.3f MB" % (fixed / 1e6, per / 1e6))

@@ -26,10 +26,14 @@ for s in $SCENES; do
     echo "$s pmc pass $i exit=$?"
   done
   for f in 1 8 20; do
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/hbm_${s}_f${f}_fetch -- python3 tools/profile_run.py $s 1024 1920 1080 $f > $OUT/hbm_${s}_f${f}_fetch.log 2>&1
-    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/hbm_${s}_f${f}_write -- python3 tools/profile_run.py $s 1024 1920 1080 $f > $OUT/hbm_${s}_f${f}_write.log 2>&1
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/hbm_${s}_1920x1080_s1024_f${f}_fetch -- python3 tools/profile_run.py $s 1024 1920 1080 $f > $OUT/hbm_${s}_f${f}_fetch.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/hbm_${s}_1920x1080_s1024_f${f}_write -- python3 tools/profile_run.py $s 1024 1920 1080 $f > $OUT/hbm_${s}_f${f}_write.log 2>&1
     echo "$s hbm passes f=$f exit=$?"
   done
 done
+# BASELINE configs[4]: the launch shape of `bench.py --config 4 --steps 2` (two frames of 3840x2160 at 4096 spp)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/hbm_monkey_3840x2160_s4096_f2_fetch -- python3 tools/profile_run.py monkey 4096 3840 2160 2 > $OUT/hbm_config4_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/hbm_monkey_3840x2160_s4096_f2_write -- python3 tools/profile_run.py monkey 4096 3840 2160 2 > $OUT/hbm_config4_write.log 2>&1
+echo "config4 hbm passes exit=$?"
 python3 tools/summarize_profile.py $OUT $SCENES > $OUT/summary.txt
 cat $OUT/summary.txt

@@ -57,7 +57,7 @@ for s in scenes:
     for fr in (1, 8, 20):
         v = {}
         for kind, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-            for f in glob.glob(os.path.join(d, "hbm_%s_f%d_%s" % (s, fr, kind), "**", "*_counter_collection.csv"), recursive=True):
+            for f in glob.glob(os.path.join(d, "hbm_%s_1920x1080_s1024_f%d_%s" % (s, fr, kind), "**", "*_counter_collection.csv"), recursive=True):
                 rows = [row for row in csv.DictReader(open(f)) if "rt_render_kernel" in row["Kernel_Name"] and row["Counter_Name"] == cname]
                 if rows:
                     last = max(int(row["Dispatch_Id"]) for row in rows)
