@@ -189,10 +189,23 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible); --share-gpu --backend gloo rehearses on one" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+                probe = torch.zeros(1, device=dev)
+                dist.all_reduce(probe)                      # RCCL builds its communicator here, not at init
+                torch.cuda.synchronize()
+            except Exception as e:                          # noqa: BLE001  (a measurement beats no measurement: say so in the line)
+                backend_note = "nccl (RCCL) failed to initialise (%s: %s); the gather went through gloo and host memory" % (type(e).__name__, str(e)[:200])
+                try:
+                    dist.destroy_process_group()
+                except Exception:                           # noqa: BLE001
+                    pass
+                args.backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group("gloo")
 
@@ -319,6 +332,8 @@ def main():
         allr = [None] * world
         dist.all_gather_object(allr, mine)
         ranks_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": allr}
+        if backend_note:
+            ranks_info["note"] = backend_note
     out = {"metric": "Msamples/sec (WxHxspp) at %dx%d, %d bounces" % (W, H, limit), "value": value, "unit": "Msamples/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
