@@ -219,7 +219,10 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
         /* the shape with the most resident waves per CU (registers, LDS: every workgroup stages its own copy of the
          * scene); the larger workgroup on a tie (fewer copies to stage) */
         int best_waves = 0;
-        for (int nt : candidates) {
+        const int mesh_candidates[4] = {1024, 768, 512, 256};
+        const char *force_nt = getenv("RT_AMD_THREADS");            /* development: force the workgroup size */
+        for (int nt : mesh_candidates) {
+            if (force_nt && atoi(force_nt) != nt) continue;
             const size_t lds = blob_bytes + per_thread * (size_t)nt;
             if (lds > RT_LDS_LIMIT) continue;
             int nb = rt_kernel_blocks_per_cu(1, 1, nt, lds);
