@@ -693,7 +693,7 @@ extern "C" rt_status rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_came
 }
 
 /* the same for n_frames consecutive frames at once (seeds times_ms[i]): one multi-frame launch per
- * 16 frames; *frame_num advances by n_frames */
+ * 32 frames; *frame_num advances by n_frames */
 extern "C" rt_status rt_render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
                                       const int32_t *times_ms, int32_t n_frames, int32_t *frame_num, float *previous_render)
 {

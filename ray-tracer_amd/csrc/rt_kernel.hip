@@ -28,18 +28,20 @@
  *    bank-conflict-free; a box is tested once, not twice as in the reference, by carrying the
  *    entry distance instead of re-testing on pop (same predicate, same outcome);
  *  - RNG state, ray, throughput and accumulators live in registers;
- *  - one launch can render several consecutive progressive frames (rt_render_device_batch): the
- *    tickets of frame k + 1 follow those of frame k, so free waves start the next frame while the
- *    last expensive tiles of a frame finish; every frame stores its per-pixel mean in a plane of
- *    its own and rt_blend_kernel (below) folds the planes into the frame buffer in frame order.
+ *  - one launch can render several consecutive progressive frames (rt_render_device_batch): a
+ *    ticket is one tile of one frame, the host lays the tickets out longest job first over ALL
+ *    frames (rt_capi.cpp build_job_order), so every frame's expensive tiles start at once and the
+ *    cheap ones fill in behind them; every frame stores its per-pixel mean in a plane of its own and
+ *    rt_blend_kernel (below) folds the planes into the frame buffer in frame order.
  *
  * The per-pixel sections (shade / fetch / generate, the primitive tests) are in rt_pixel.h; this
  * file has the two kernels built from them - rt_render_kernel (the default) and the opt-in
  * rt_render_pool_kernel - and the launchers.
  *
  * No MFMA: there is no dense contraction anywhere in this workload.
- * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the reference's a*b+c are two
- * roundings; contraction would change hit/miss decisions).
+ * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize (the reference's a*b+c
+ * are two roundings: contraction would change hit/miss decisions; the SLP vectorizer's packed f32
+ * pairs cost 40 % more registers and 10 % of the time).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
