@@ -34,7 +34,8 @@ class Material(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("samples", "bounce_iters", "hits", "rng_draws", "sphere_tests", "sphere_hits", "tri_tests", "box_tests")]
+                ("samples", "bounce_iters", "hits", "rng_draws", "sphere_tests", "sphere_hits", "tri_tests", "box_tests",
+                 "dead_sphere_tests", "dead_tri_tests", "dead_box_tests")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -57,6 +57,9 @@ void orc_material_image(orc_material *m, int w, int h, const float *rgb, float s
 typedef struct {
     uint64_t samples, bounce_iters, hits, rng_draws;
     uint64_t sphere_tests, sphere_hits, tri_tests, box_tests;
+    /* the reference's dead get_ray_collision per pixel (src/raytracer.cu:98: its result is discarded): its
+     * intersection tests, kept apart so that the per-sample figures above stay the live work's */
+    uint64_t dead_sphere_tests, dead_tri_tests, dead_box_tests;
 } orc_stats;
 
 typedef struct orc_scene orc_scene;
