@@ -200,3 +200,25 @@ def test_reference_camera_floats_reproduce_the_recorded_reference_frames(rt, orc
     assert eq(data.previous_render, want)
     assert hashlib.sha256(data.previous_render.tobytes()).hexdigest()[:16] == rec["sha256_prefix"]
     assert float("%.9g" % data.previous_render.mean(dtype=np.float64)) == rec["mean"]
+
+
+def test_bvh_mesh_equals_brute_force_triangles(rt, ctx, models_dir, golden_meta):
+    """SURVEY.md App. A.10 recorded of the reference: the monkey through its BVH and as 723 top-level triangles
+    render bit-identically at 256x256, 16 spp, limit 8.  Same here on the GPU: the mesh kernel (compact reference
+    tree in LDS) and the no-mesh kernel walking a 725-entry object list give the same frame, which is also the
+    committed det-mode hash of that configuration."""
+    import os
+    objs, sky = rt.scenes.monkey()
+    m = rt.ObjFileMesh(os.path.join(models_dir, "low_poly_monkey.obj"))
+    for t in objs[0][2]:
+        getattr(m, t[0])(*t[1:])
+    tris = m.triangles().reshape(-1, 3, 3)
+    brute = [("triangle", tuple(t[0]), tuple(t[1]), tuple(t[2]), objs[0][3]) for t in tris] + list(objs[1:])
+    frames = []
+    for description in (objs, brute):
+        scene = ctx.commit(rt.SceneObjects(description))
+        data = rt.VariableRenderData(256, 256)
+        rt.render(ctx, scene, rt.Camera(256, 256), rt.RenderData(16, 8, True, sky), data, golden_meta["time_ms"])
+        frames.append(data.previous_render.copy())
+    assert eq(frames[0], frames[1])
+    assert hashlib.sha256(frames[0].tobytes()).hexdigest() == golden_meta["sha256_256x256_s16"]["monkey"]["sha256"]
