@@ -152,6 +152,20 @@ def test_stated_tolerance_det_mode_vs_the_reference_build(orc, rt, models_dir, g
         assert np.array_equal(ref.view(np.uint32), same_cam.view(np.uint32)), name
         diff = np.abs(ref.astype(np.float64) - own_cam.astype(np.float64))
         assert int((ref != own_cam).any(axis=2).sum()) == npix and float(diff.max()) == linf, name
+    # The survey made this very experiment on the reference itself (hard part 1): "changing only
+    # viewport_width by 1 ULP (glibc's runtime tanf(FOV/2) = 0x3f13cd3b vs the compile-time-folded, correctly-rounded
+    # 0x3f13cd3a - which one you get depends on whether the compiler folds src/camera.cu:47) flipped 2 of 65,536
+    # pixels at 16 spp by 0.375-0.47".  rt_tanf gives the folded value, so the product's default camera IS the
+    # reference's camera under a constant-folding compiler, and the two pixels and their differences are the survey's.
+    L = orc.lib()
+    fov_half = np.float32(np.float32(60) * (np.float32(3.141592653589793) / np.float32(180))) / np.float32(2)
+    assert np.float32(L.orc_math_tanf(float(fov_half), orc.MATH_DET)).view(np.uint32) == 0x3f13cd3a
+    assert np.float32(L.orc_math_tanf(float(fov_half), orc.MATH_LIBM)).view(np.uint32) == 0x3f13cd3b
+    objs, sky = rt.scenes.monkey()
+    a = orc.Scene(objs, orc.MATH_LIBM, models_dir).render(cam_libm, 256, 256, 16, 8, sky)
+    b = orc.Scene(objs, orc.MATH_LIBM, models_dir).render(cam_det, 256, 256, 16, 8, sky)       # same math, folded camera
+    d = np.abs(a.astype(np.float64) - b).max(axis=2)
+    assert sorted(float(v) for v in d[d > 0]) == [0.375, 0.46875]
 
 
 # SURVEY.md §3.5 "Measured shape of the hot loops": per-sample counters of an INSTRUMENTED COPY OF THE REFERENCE
