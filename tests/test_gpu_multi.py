@@ -222,3 +222,27 @@ def test_bvh_mesh_equals_brute_force_triangles(rt, ctx, models_dir, golden_meta)
         frames.append(data.previous_render.copy())
     assert eq(frames[0], frames[1])
     assert hashlib.sha256(frames[0].tobytes()).hexdigest() == golden_meta["sha256_256x256_s16"]["monkey"]["sha256"]
+
+
+def test_flat_box_drop_quirk_on_the_device(rt, orc, ctx, models_dir):
+    """a BVH leaf box of zero thickness is never entered (strict `tmin < tmax`), so the
+    UNROTATED cube.obj loses most of its faces in the reference.  The HIP traversal must lose exactly the same
+    ones: unrotated cube + ground + sky against the oracle, bit for bit, and it must differ from the same triangles
+    rendered as top-level objects (which lose nothing)."""
+    mat = ("standard", (0.8, 0.4, 0.2), 0)
+    ground = ("sphere", (0, -100.5, 1.5), 100, ("standard", (0.5, 0.5, 0.5), 0))
+    sky = (0.8, 1.0, 1.0)
+    mesh = [("obj", "cube.obj", [("enlarge", 0.3), ("rotate", 0.0, 0.0, 0.0), ("translate", 0, 0, 1.8)], mat), ground]
+    m = rt.ObjFileMesh(__import__("os").path.join(models_dir, "cube.obj"))
+    m.enlarge(0.3); m.translate(0, 0, 1.8)
+    brute = [("triangle", tuple(t[0]), tuple(t[1]), tuple(t[2]), mat) for t in m.triangles().reshape(-1, 3, 3)] + [ground]
+    W, H, spp = 160, 120, 8
+    frames = {}
+    for key, description in (("mesh", mesh), ("brute", brute)):
+        scene = ctx.commit(rt.SceneObjects(description))
+        data = rt.VariableRenderData(W, H)
+        rt.render(ctx, scene, rt.Camera(W, H), rt.RenderData(spp, 8, True, sky), data, 4242)
+        want = orc.Scene(description, orc.MATH_DET, models_dir).render(rt.Camera(W, H).floats(), W, H, spp, 8, sky, time_ms=4242)
+        assert eq(data.previous_render, want), key
+        frames[key] = data.previous_render.copy()
+    assert (frames["mesh"] != frames["brute"]).any(axis=2).sum() > 200        # the quirk is visible

@@ -222,3 +222,39 @@ def test_bvh_mesh_equals_brute_force_triangles_as_the_survey_recorded(orc, rt, m
     a = orc.Scene(objs, orc.MATH_LIBM, models_dir).render(cam, 128, 128, 8, 8, sky)
     b = orc.Scene(brute, orc.MATH_LIBM, models_dir).render(cam, 128, 128, 8, 8, sky)
     assert len(brute) == 725 and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_flat_box_drop_quirk_as_the_survey_observed(orc, rt, models_dir):
+    """the reference's strict `tmin < tmax` slab test can never enter a box of zero thickness,
+    so "models/cube.obj *unrotated* renders with most faces missing (a single triangle is visible from the default
+    camera); rotated by (0.4, 0.7, 0) it renders as a full cube".  The oracle shows the same: through the BVH the
+    unrotated cube covers less than half the pixels it covers when the same 12 triangles are top-level objects (603
+    of 2,025 at 128x128); the rotated cube loses nothing."""
+    W = H = 128
+    cam = orc.camera_default(W, H, orc.MATH_LIBM)
+    cp, tl, du, dv = cam[0:3], cam[3:6], cam[6:9], cam[9:12]
+    mat = ("standard", (0.8, 0.4, 0.2), 0)
+
+    def hit_count(description):
+        sc = orc.Scene(description, orc.MATH_LIBM, models_dir)
+        n = 0
+        for y in range(H):
+            for x in range(W):
+                d = (tl + du * np.float32(x) + dv * np.float32(y) - cp).astype(np.float32)
+                d = (d / np.float32(np.sqrt(np.float32((d * d).sum())))).astype(np.float32)
+                n += int(sc.trace_one(cp, d)[0])
+        return n
+
+    def as_triangles(rot):
+        m = rt.ObjFileMesh(os.path.join(models_dir, "cube.obj"))
+        m.enlarge(0.3); m.rotate(*rot); m.translate(0, 0, 1.8)
+        return [("triangle", tuple(t[0]), tuple(t[1]), tuple(t[2]), mat) for t in m.triangles().reshape(-1, 3, 3)]
+
+    for rot, lost in (((0.0, 0.0, 0.0), True), ((0.4, 0.7, 0.0), False)):
+        mesh = [("obj", "cube.obj", [("enlarge", 0.3), ("rotate",) + rot, ("translate", 0, 0, 1.8)], mat)]
+        through_bvh, brute = hit_count(mesh), hit_count(as_triangles(rot))
+        assert brute > 500
+        if lost:
+            assert 0.2 * brute < through_bvh < 0.5 * brute          # 603 of 2,025 pixels: most of the cube is missing
+        else:
+            assert through_bvh == brute
