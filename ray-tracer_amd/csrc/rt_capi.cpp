@@ -214,7 +214,17 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
     s->threads = 0;
     (void)hipSetDevice(ctx->device);
     if (!s->flat.has_mesh) {
-        if (blob_bytes <= RT_LDS_LIMIT) { s->threads = 256; s->lds_bytes = blob_bytes; }
+        /* 256-thread workgroups (six per CU) unless the object list is so long that only one or two copies of it
+         * fit a CU's LDS: then the workgroup that keeps the most waves resident */
+        int best_waves = 0;
+        const int flat_candidates[4] = {256, 512, 768, 1024};
+        for (int nt : flat_candidates) {
+            if (blob_bytes > RT_LDS_LIMIT) break;
+            int nb = rt_kernel_blocks_per_cu(0, 1, nt, blob_bytes);
+            if (nb > RT_MAX_BLOCKS_PER_CU) nb = RT_MAX_BLOCKS_PER_CU;
+            if (nb < 1) nb = 1;
+            if (nb * (nt / 64) > best_waves) { best_waves = nb * (nt / 64); s->threads = nt; s->lds_bytes = blob_bytes; s->blocks_per_cu = nb; }
+        }
     } else {
         /* the shape with the most resident waves per CU (registers, LDS: every workgroup stages its own copy of the
          * scene); the larger workgroup on a tie (fewer copies to stage) */
@@ -260,7 +270,7 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
             return set_err(ctx, RT_ERR_UNSUPPORTED, "BVH too deep for the per-lane LDS traversal stack");
         }
     }
-    if (!s->pool && (!s->flat.has_mesh || !s->scene_in_lds)) {
+    if (!s->pool && !s->scene_in_lds) {
         /* (a 256-thread workgroup is admitted at most 6 times at this kernel's SGPR count, whatever the API says:
          * MI355X_MICROARCH.md, residency; surplus workgroups would only queue behind the resident ones) */
         int nb = rt_kernel_blocks_per_cu(s->flat.has_mesh ? 1 : 0, s->scene_in_lds, s->threads, s->lds_bytes);
