@@ -73,12 +73,14 @@ struct rt_ctx {
     int lpt = 1;                         /* RT_AMD_LPT=0: the round-1 ticket order (heavy tiles of frame 0, 1, ... first) */
     int lpt_top = 1 << 30;               /* RT_AMD_LPT_TOP: at most this many tiles (most expensive first) are scheduled by cost */
     int heavy_first = 1;                 /* RT_AMD_HEAVY_FIRST=0 disables */
-    int work_threshold = 8;      /* lanes; RT_AMD_WORK_THRESHOLD overrides (tuning: tools/ab_threshold.py) */
-    int descend_keep = 24;       /* RT_AMD_DESCEND_KEEP (0..64): 0 = run every descent to its end */
+    /* scheduling thresholds (defaults in rt_device_scene.h) */
+    int work_threshold = RT_DEF_WORK_THRESHOLD;      /* lanes; RT_AMD_WORK_THRESHOLD */
+    int descend_keep = RT_DEF_DESCEND_KEEP;       /* RT_AMD_DESCEND_KEEP (0..64): 0 = run every descent to its end */
     int tile_scatter = 1;        /* RT_AMD_TILE_SCATTER=0: hand tiles out in raster order */
-    int ready_break = 40;        /* lanes; RT_AMD_READY_BREAK overrides; 65 = never */
-    int hit_break = 24;          /* lanes; RT_AMD_HIT_BREAK */
-    int shade_batch = 40;        /* lanes; RT_AMD_SHADE_BATCH (1..64) */
+    int ready_break = RT_DEF_READY_BREAK;        /* lanes; RT_AMD_READY_BREAK; 65 = never */
+    int hit_break = RT_DEF_HIT_BREAK;          /* lanes; RT_AMD_HIT_BREAK */
+    int hit_low = RT_DEF_HIT_LOW, mix_break = RT_DEF_MIX_BREAK;   /* RT_AMD_HIT_LOW, RT_AMD_MIX_BREAK (0 = that rule off) */
+    int shade_batch = RT_DEF_SHADE_BATCH;        /* lanes; RT_AMD_SHADE_BATCH (1..64) */
     int use_pool = 0;            /* RT_AMD_POOL=1: mesh scenes through the workgroup ray pool (rt_render_pool_kernel); an experiment, slower */
     int pool_fill = 16, pool_low = 16, pool_leaf_batch = 48;    /* RT_AMD_POOL_FILL / _LOW / _LEAF_BATCH */
 };
@@ -157,6 +159,8 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (const char *e = getenv("RT_AMD_LPT")) ctx->lpt = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_LPT_TOP")) { int v = atoi(e); if (v >= 0) ctx->lpt_top = v; }
     if (const char *e = getenv("RT_AMD_HIT_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->hit_break = v; }
+    if (const char *e = getenv("RT_AMD_HIT_LOW")) { int v = atoi(e); if (v >= 0 && v <= 65) ctx->hit_low = v; }
+    if (const char *e = getenv("RT_AMD_MIX_BREAK")) { int v = atoi(e); if (v >= 0 && v <= 130) ctx->mix_break = v; }
     if (const char *e = getenv("RT_AMD_SHADE_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->shade_batch = v; }
     if (const char *e = getenv("RT_AMD_POOL")) ctx->use_pool = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_POOL_FILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->pool_fill = v; }
@@ -560,6 +564,8 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
     a.work_threshold = ctx->work_threshold;
     a.ready_break = ctx->ready_break;
     a.hit_break = ctx->hit_break;
+    a.hit_low = ctx->hit_low > 0 && ctx->mix_break > 0 ? ctx->hit_low : ctx->hit_break;
+    a.mix_break = ctx->hit_low > 0 && ctx->mix_break > 0 ? ctx->mix_break : 1000;
     a.shade_batch = ctx->shade_batch;
     a.pool_fill = ctx->pool_fill;
     a.pool_low = ctx->pool_low;

@@ -33,6 +33,16 @@
 #define RT_FRAME_BITS 5               /* a pixel keeps the index of its frame within the launch in this many bits */
 #define RT_MAX_BATCH_FRAMES (1 << RT_FRAME_BITS)   /* frames one launch can render */
 #define RT_SMALL_WG_WAVES 5            /* workgroups of fewer than 1024 threads are compiled for this many waves per SIMD (<= 96 VGPRs) */
+/* Defaults of the render kernel's scheduling thresholds (lanes of a wave; see rt_kernel.hip; RT_AMD_* overrides them).
+ * None of them changes an image.  Values: same-box sweeps over four scenes in the multi-frame regime,
+ * profiles/r02/experiments/.  (Compiling them in as immediates instead of launch arguments was measured: no difference.) */
+#define RT_DEF_WORK_THRESHOLD 8      /* traversal steps run while at least this many lanes traverse */
+#define RT_DEF_READY_BREAK 40        /* ... unless this many lanes have cheap work (generate / fetch / next mesh / a miss) */
+#define RT_DEF_HIT_BREAK 40          /* ... or this many hold a hit to shade */
+#define RT_DEF_HIT_LOW 16            /* ... or at least this many hold a hit and, with the cheap-work lanes, they are */
+#define RT_DEF_MIX_BREAK 40          /*     this many together */
+#define RT_DEF_DESCEND_KEEP 24       /* the descend loop ends once fewer than this many 64ths of its lanes remain */
+#define RT_DEF_SHADE_BATCH 40        /* scenes without a mesh: hits are shaded once this many lanes hold one */
 #define RT_JOB_FRAME_SHIFT 22          /* a job = tile | frame << 22 (2^28 pixels are 2^22 tiles) */
 #define RT_JOB_TILE_MASK 0x003fffffu
 #define RT_INF_F 1073741824.0f       /* reference `1 << 31 - 1` == 1 << 30, src/objects.cu:6 */
@@ -126,6 +136,7 @@ typedef struct {
     int32_t descend_keep;          /* leave the descend loop when fewer than descend_keep/64 of its lanes remain */
     int32_t ready_break;           /* ... unless at least this many lanes are ready to shade / generate */
     int32_t hit_break;             /* ... or this many hold a hit to shade */
+    int32_t hit_low, mix_break;    /* ... or at least hit_low hold a hit and hits + cheap-work lanes together reach mix_break */
     int32_t shade_batch;           /* scenes without a mesh: hits are shaded once this many lanes hold one */
     /* pooled kernel */
     int32_t pool_fill;             /* a box-test executor hands on / takes on rays once this many of its lanes are not stepping */

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : RT_SMALL_WG_WAVES) void rt_ren
             const int n_hit = __popcll(__ballot(p.mode == M_SHADE));
             const bool others = __ballot(p.mode == M_GEN || (p.mode == M_FETCH && !ch.exhausted)) != 0ull;
             const int n_trav = __popcll(__ballot(p.mode == M_WAIT));
-            if (n_hit > 0 && (HAS_MESH ? (n_hit >= a.hit_break || n_trav < a.work_threshold) : (n_hit >= a.shade_batch || !others))) {
+            if (n_hit > 0 && (HAS_MESH ? (n_hit >= a.hit_low || n_trav < a.work_threshold)
+                                        : (n_hit >= a.shade_batch || !others))) {
                 if (p.mode == M_SHADE) {
                     RT_STAT(ST_SHADE);
                     px_shade(p, a, f, L);
@@ -207,7 +208,14 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : RT_SMALL_WG_WAVES) void rt_ren
                 const bool is_hit = p.mode == M_SHADE && p.best_obj >= 0;
                 const int n_hit = __popcll(__ballot(is_hit));
                 const int n_light = __popcll(__ballot(p.mode != M_WAIT && p.mode != M_DONE && !is_hit));
-                if (n_hit + n_light > 0 && (n_active < a.work_threshold || n_hit >= a.hit_break || n_light >= a.ready_break)) break;
+                /* ... or a smaller batch of hits that, together with the cheap-work lanes, is worth the round: where
+                 * every traversal ends in a hit (a closed scene) hits fill a big batch fast and big batches are what
+                 * the 700-instruction shade wants; where most rays escape (an open scene) hits are rare, the lanes
+                 * holding one would idle for long, and the round is paid for by the escaped lanes anyway */
+                if (n_hit + n_light > 0 &&
+                    (n_active < a.work_threshold || n_hit >= a.hit_break ||
+                     n_light >= a.ready_break ||
+                     (n_hit >= a.hit_low && n_hit + n_light >= a.mix_break))) break;
 #if defined(RT_COSTMAP) && RT_COSTMAP == 2
                 p.c_wsteps += 1;      /* wave-level macro steps this lane lived through */
 #endif
