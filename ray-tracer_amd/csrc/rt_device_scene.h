@@ -38,7 +38,7 @@
  * profiles/r02/experiments/.  (Compiling them in as immediates instead of launch arguments was measured: no difference.) */
 #define RT_DEF_WORK_THRESHOLD 8      /* traversal steps run while at least this many lanes traverse */
 #define RT_DEF_READY_BREAK 40        /* ... unless this many lanes have cheap work (generate / fetch / next mesh / a miss) */
-#define RT_DEF_HIT_BREAK 40          /* ... or this many hold a hit to shade */
+#define RT_DEF_HIT_BREAK 24          /* ... or this many hold a hit to shade */
 #define RT_DEF_HIT_LOW 16            /* ... or at least this many hold a hit and, with the cheap-work lanes, they are */
 #define RT_DEF_MIX_BREAK 40          /*     this many together */
 #define RT_DEF_DESCEND_KEEP 24       /* the descend loop ends once fewer than this many 64ths of its lanes remain */

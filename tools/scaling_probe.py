@@ -1,7 +1,7 @@
 """What the ranks of an N-GPU strong-scaling run do, measured on ONE GPU (development tool): for N = 1, 2, 4, 8
 renders, one rank after another, the bands each rank would own of `frames` progressive frames (one multi-frame
 launch per rank, as bench.py does) and prints the slowest rank's kernel time; T(1)/T(N) projects the strong-scaling
-speed-up (the gather adds ~0.1 ms per rank).  usage: scaling_probe.py [spp] [frames] [W] [H] [scene]"""
+speed-up (the gather adds ~0.1 ms per rank).  usage: scaling_probe.py [spp] [frames] [W] [H] [scene]; RT_PROBE_N=1,8 picks the Ns"""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +16,7 @@ objs, sky = rt.scenes.CONFIG_SCENES[name]()
 cam, rd = rt.Camera(W, H), rt.RenderData(spp, 8, True, sky)
 st = torch.cuda.current_stream().cuda_stream
 t1 = None
-for n in (1, 2, 4, 8):
+for n in [int(x) for x in os.environ.get("RT_PROBE_N", "1,2,4,8").split(",")]:
     per_rank = []
     for r in range(n):
         ctx = rt.Context(0)                      # a rank is a process with its own context: its own tile-order cache
