@@ -1,0 +1,23 @@
+#!/bin/bash
+# Copies what tools/profile_all.sh <tag> left under gpurun_out/prof_<tag> (scratch, merged back by gpurun) into
+# profiles/<tag>/ (tracked) under the names profiles/README.md lists.  usage: tools/collect_profiles.sh <tag>
+set -e
+TAG=${1:-r02}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+G=$ROOT/gpurun_out/prof_$TAG
+P=$ROOT/profiles/$TAG
+mkdir -p $P
+cp $G/summary.txt $P/rocprofv3_summary.txt
+[ -f $G/fit_traffic.txt ] && cp $G/fit_traffic.txt $P/
+[ -f $G/traffic.json ] && cp $G/traffic.json $ROOT/profiles/traffic.json
+for s in monkey three_sphere cube; do
+  [ -d $G/stats_$s ] || continue
+  cp $G/stats_$s/*/*_kernel_stats.csv $P/kernel_stats_$s.csv
+  cp $G/stats_$s/*/*_kernel_trace.csv $P/kernel_trace_$s.csv
+  cp $G/bench_under_rocprof_$s.json $P/
+  for i in 1 2 3; do cp $G/pmc${i}_$s/*/*_counter_collection.csv $P/pmc${i}_${s}_counter_collection.csv; done
+done
+for d in $G/hbm_*_fetch $G/hbm_*_write; do
+  [ -d $d ] && cp $d/*/*_counter_collection.csv $P/$(basename $d)_counter_collection.csv
+done
+echo "collected into $P"
