@@ -246,3 +246,23 @@ def test_flat_box_drop_quirk_on_the_device(rt, orc, ctx, models_dir):
         assert eq(data.previous_render, want), key
         frames[key] = data.previous_render.copy()
     assert (frames["mesh"] != frames["brute"]).any(axis=2).sum() > 200        # the quirk is visible
+
+
+def test_more_frames_than_one_launch_holds(rt, orc, models_dir):
+    """40 progressive frames in one call: rt_render_frames and rt_render_multi cut them into launches of at most 32
+    frames (RT_MAX_BATCH_FRAMES), the second launch continuing from the first one's image; both must equal the
+    oracle's 40-frame loop"""
+    objs, sky = rt.scenes.cube()
+    W, H, spp = 64, 48, 2
+    times = list(range(1000, 1040))
+    want = oracle_progressive(orc, objs, models_dir, rt.Camera(W, H).floats(), W, H, spp, 8, sky, times)
+    ctxs = [rt.Context(0) for _ in range(2)]
+    so = rt.SceneObjects(objs)
+    scenes = [c.commit(so) for c in ctxs]
+    cam, rd = rt.Camera(W, H), rt.RenderData(spp, 8, True, sky)
+    one = rt.VariableRenderData(W, H)
+    rt.render_frames(ctxs[0], scenes[0], cam, rd, one, times)
+    assert one.frame_num == 40 and eq(one.previous_render, want)
+    many = rt.VariableRenderData(W, H)
+    rt.render_multi(ctxs, scenes, cam, rd, many, times)
+    assert many.frame_num == 40 and eq(many.previous_render, want)
