@@ -1,0 +1,37 @@
+"""One-off parity soak (development tool): many seeded random mixed scenes (tests/test_gpu_parity.py::_random_scene),
+each rendered by a one-frame launch and by a three-frame launch (twice: the second runs on the measured-cost
+schedule), against the CPU oracle, bit for bit.   python tools/soak_parity.py <first seed> <count>"""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+rt = importlib.import_module("ray-tracer_amd")
+from oracle import binding as orc
+from test_gpu_parity import _random_scene
+first, count = int(sys.argv[1]), int(sys.argv[2])
+ctx = rt.Context(0)
+md = rt.scenes.models_dir()
+bad = 0
+for seed in range(first, first + count):
+    objs, sky = _random_scene(seed)
+    W, H, spp, limit = 96 + 8 * (seed % 5), 64 + 8 * (seed % 3), 3 + seed % 3, 2 + seed % 7
+    cam = rt.Camera(W, H)
+    scene = ctx.commit(rt.SceneObjects(objs))
+    o = orc.Scene(objs, orc.MATH_DET, md)
+    want1 = o.render(cam.floats(), W, H, spp, limit, sky, time_ms=seed)
+    want = want1
+    for k in (1, 2):
+        want = o.render(cam.floats(), W, H, spp, limit, sky, time_ms=seed + k, frame_num=k, prev=want)
+    rd = rt.RenderData(spp, limit, True, sky)
+    d = rt.VariableRenderData(W, H)
+    rt.render(ctx, scene, cam, rd, d, seed)
+    ok = np.array_equal(d.previous_render.view(np.uint32), want1.view(np.uint32))
+    for rep in range(2):
+        d3 = rt.VariableRenderData(W, H)
+        rt.render_frames(ctx, scene, cam, rd, d3, [seed, seed + 1, seed + 2])
+        ok = ok and np.array_equal(d3.previous_render.view(np.uint32), want.view(np.uint32))
+    if not ok:
+        bad += 1
+        print("MISMATCH seed", seed, flush=True)
+print("soak: %d scenes, %d mismatches" % (count, bad), flush=True)
+sys.exit(1 if bad else 0)
