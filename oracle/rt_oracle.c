@@ -180,14 +180,16 @@ static inline v3 texture_colour(const orc_material *m, float u, float v)
         case ORC_TEX_COLOUR: return v3_from(m->colour);                 /* :75-77 */
         case ORC_TEX_GRADIENT: return v3_make(u, v, 0);                 /* :80-82 */
         case ORC_TEX_CHECKERBOARD: {                                    /* :90-99 */
-            int uc = (int)(u * m->num_squares);
-            int vc = (int)(v * m->num_squares);
-            return ((uc + vc) % 2 == 0) ? v3_from(m->light) : v3_from(m->dark);
+            /* float -> int as CUDA converts (NaN -> 0, saturating), rt_math.h rt_f2i: a plain C cast is undefined
+             * for the NaN a sphere's u can be at the pole (asin of 1 + ulp), and x86 would give INT_MIN */
+            int uc = rt_f2i(u * m->num_squares);
+            int vc = rt_f2i(v * m->num_squares);
+            return ((int)((uint32_t)uc + (uint32_t)vc) % 2 == 0) ? v3_from(m->light) : v3_from(m->dark);
         }
         case ORC_TEX_IMAGE: {                                           /* :119-124 */
-            int uc = (int)((m->img_w - 1) * u);
-            int vc = (int)((m->img_h - 1) * v);
-            int idx = vc * m->img_w + uc;
+            int uc = rt_f2i((m->img_w - 1) * u);
+            int vc = rt_f2i((m->img_h - 1) * v);
+            int idx = (int)((uint32_t)vc * (uint32_t)m->img_w + (uint32_t)uc);
             /* the reference indexes unchecked; an out-of-range texel is clamped here (and in the kernel) */
             if (idx < 0) idx = 0;
             if (idx > m->img_w * m->img_h - 1) idx = m->img_w * m->img_h - 1;
@@ -982,7 +984,7 @@ void orc_to_rgba8(const float *rgb, int W, int H, uint8_t *out)
 {   /* parse_pixel_colours src/main.cu:343-371: int(px*255), clamp 0..255, alpha 255 */
     for (int i = 0; i < W * H; i++) {
         for (int c = 0; c < 3; c++) {
-            int colour = (int)(rgb[3 * i + c] * 255);
+            int colour = rt_f2i(rgb[3 * i + c] * 255);
             if (colour > 255) colour = 255; else if (colour < 0) colour = 0;
             out[4 * i + c] = (uint8_t)colour;
         }

@@ -726,7 +726,7 @@ __global__ void rt_rgba8_kernel(const float *rgb, int n_pixels, uint8_t *out)
     if (i >= n_pixels) return;
     uint32_t packed = 0xff000000u;
     for (int c = 0; c < 3; c++) {
-        int colour = (int)(rgb[3 * i + c] * 255.0f);
+        int colour = rt_f2i(rgb[3 * i + c] * 255.0f);
         colour = colour > 255 ? 255 : (colour < 0 ? 0 : colour);
         packed |= (uint32_t)colour << (8 * c);
     }

@@ -31,6 +31,20 @@
 #endif
 
 RT_HD uint32_t rt_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+
+/* float -> int the way the reference's platform converts (CUDA cvt.rzi.s32.f32; gfx950's v_cvt_i32_f32 does the
+ * same): truncation, NaN -> 0, out of range -> saturated.  C leaves NaN and out-of-range conversions undefined and
+ * x86 returns INT_MIN for them, so a plain cast would make the CPU oracle and the GPU disagree exactly where the
+ * reference's texture lookups (src/material.cu:90-99, :119-124) and display conversion (src/main.cu:343-371) can
+ * meet such a value: a sphere's texture u is asin((P.y - c.y) / r), and at the pole that quotient exceeds 1 by an
+ * ulp now and then -> NaN.  (Found by tools/soak_parity.py: one pixel in 3,000 random scenes.) */
+RT_HD int rt_f2i(float x)
+{
+    if (x != x) return 0;
+    if (x >= 2147483648.0f) return 2147483647;
+    if (x <= -2147483648.0f) return -2147483647 - 1;
+    return (int)x;
+}
 RT_HD float rt_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 
 /* ---- natural logarithm ------------------------------------------------------------

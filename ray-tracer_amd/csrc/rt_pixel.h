@@ -354,15 +354,15 @@ __device__ __forceinline__ void px_shade(Px &p, const rt_kernel_args &a, const F
             } else if (tex == 3) {
                 /* image src/material.cu:119-124: nearest texel; an out-of-range index is clamped */
                 const int iw = (int)__float_as_uint(ma.x), ih = (int)__float_as_uint(ma.y);
-                const int uc = (int)((float)(iw - 1) * tex_u), vc = (int)((float)(ih - 1) * tex_v);
-                int idx = vc * iw + uc;
+                const int uc = rt_f2i((float)(iw - 1) * tex_u), vc = rt_f2i((float)(ih - 1) * tex_v);
+                int idx = (int)((uint32_t)vc * (uint32_t)iw + (uint32_t)uc);       /* wraps like the 32-bit machine arithmetic */
                 idx = idx < 0 ? 0 : (idx > iw * ih - 1 ? iw * ih - 1 : idx);
                 const float *tx = a.tex_data + (size_t)__float_as_uint(ma.z) + 3 * (size_t)idx;
                 tc = v3(tx[0], tx[1], tx[2]);
             } else {
                 const int nsq = (int)(packed >> 8);                      /* checkerboard :90-99 */
-                int uc = (int)(tex_u * (float)nsq), vc = (int)(tex_v * (float)nsq);
-                tc = ((uc + vc) % 2 == 0) ? v3(ma.x, ma.y, ma.z) : v3(mb.x, mb.y, mb.z);
+                const int uc = rt_f2i(tex_u * (float)nsq), vc = rt_f2i(tex_v * (float)nsq);
+                tc = ((int)((uint32_t)uc + (uint32_t)vc) % 2 == 0) ? v3(ma.x, ma.y, ma.z) : v3(mb.x, mb.y, mb.z);
             }
             p.thr = p.thr * tc;
         }

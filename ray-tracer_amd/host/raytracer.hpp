@@ -454,7 +454,10 @@ inline std::vector<uint8_t> parse_pixel_colours(const std::vector<float> &pixel_
     std::vector<uint8_t> out((size_t)width * (size_t)height * 4);
     for (size_t i = 0; i < (size_t)width * (size_t)height; i++) {
         for (int k = 0; k < 3; k++) {
-            int colour = (int)(pixel_colours[3 * i + k] * 255);
+            /* a defined conversion (NaN -> 0, saturating), the same as rt_to_rgba8_device: a plain cast of a NaN or an
+             * infinite value is undefined in C++ */
+            const float scaled = pixel_colours[3 * i + k] * 255;
+            int colour = scaled != scaled ? 0 : (scaled >= 2147483648.0f ? 2147483647 : (scaled <= -2147483648.0f ? -2147483647 - 1 : (int)scaled));
             if (colour > 255) colour = 255; else if (colour < 0) colour = 0;
             out[4 * i + k] = (uint8_t)colour;
         }

@@ -266,3 +266,25 @@ def test_more_frames_than_one_launch_holds(rt, orc, models_dir):
     many = rt.VariableRenderData(W, H)
     rt.render_multi(ctxs, scenes, cam, rd, many, times)
     assert many.frame_num == 40 and eq(many.previous_render, want)
+
+
+def test_nan_texture_coordinate_at_a_sphere_pole(rt, orc, ctx, models_dir):
+    """Found by tools/soak_parity.py (seed 7895, one pixel in 3,000 random scenes): at a sphere's pole
+    (P.y - c.y) / r can exceed 1 by an ulp, asin gives NaN, and the image / checkerboard lookups convert a NaN u to
+    int - undefined in C (x86: INT_MIN), 0 on CUDA and on gfx950.  rt_math.h's rt_f2i defines it (NaN -> 0,
+    saturating) for the oracle and the kernel alike; this is the scene and the pixel that differed."""
+    rng = np.random.default_rng(5)
+    img = rng.uniform(0, 1, (7, 4, 3)).astype(np.float32)
+    sky = (0.8, 1.0, 1.0)
+    centre, radius = (-0.5656471126252296, -0.4661420880950526, 2.246162948711449), 0.11503499970308974
+    W, H = 96, 80
+    for mat in (("image", img, 0.0), ("checkerboard", (0.9, 0.8, 0.1), (0.1, 0.2, 0.3), 7, 0.0), ("gradient", 0.0)):
+        objs = [("sphere", centre, radius, mat)]
+        scene = ctx.commit(rt.SceneObjects(objs))
+        for t in (7895, 7896, 7897, 1, 2):
+            data = rt.VariableRenderData(W, H)
+            rt.render(ctx, scene, rt.Camera(W, H), rt.RenderData(2, 2, True, sky), data, t)
+            want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(W, H).floats(), W, H, 2, 2, sky, time_ms=t)
+            a, b = data.previous_render, want
+            same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))      # a NaN colour (gradient of a NaN u) is a NaN on both sides
+            assert same.all(), (mat[0], t, int((~same).any(axis=2).sum()))
