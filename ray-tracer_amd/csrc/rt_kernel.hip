@@ -709,7 +709,7 @@ __global__ void rt_blend_kernel(const float *partial, long long plane_floats, in
         const float previous_sum = r * (float)n;
         r = (partial[(long long)k * plane_floats + i] + previous_sum) / (float)(n + 1);
     }
-    frame[i] = r;
+    frame[i] = rt_canon_nan(r);
 }
 
 extern "C" hipError_t rt_launch_blend(const float *partial, long long plane_floats, int num_frames, int frame_num, float *frame, long long n_floats, hipStream_t stream)

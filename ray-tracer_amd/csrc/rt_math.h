@@ -31,6 +31,7 @@
 #endif
 
 RT_HD uint32_t rt_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+RT_HD float rt_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 
 /* float -> int the way the reference's platform converts (CUDA cvt.rzi.s32.f32; gfx950's v_cvt_i32_f32 does the
  * same): truncation, NaN -> 0, out of range -> saturated.  C leaves NaN and out-of-range conversions undefined and
@@ -38,6 +39,12 @@ RT_HD uint32_t rt_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return
  * reference's texture lookups (src/material.cu:90-99, :119-124) and display conversion (src/main.cu:343-371) can
  * meet such a value: a sphere's texture u is asin((P.y - c.y) / r), and at the pole that quotient exceeds 1 by an
  * ulp now and then -> NaN.  (Found by tools/soak_parity.py: one pixel in 3,000 random scenes.) */
+/* A NaN that reaches the frame buffer is stored as THE quiet NaN 0x7fc00000.  The reference can produce one (a
+ * GRADIENT-textured sphere hit at its pole: the texture colour is the NaN u or v itself, src/material.cu:80-82) and
+ * leaves its sign and payload to the platform - x86 and gfx950 already differ in the NaN that 0/0 gives - so
+ * "bit-identical frames" needs one representation. */
+RT_HD float rt_canon_nan(float x) { return x != x ? rt_u2f(0x7fc00000u) : x; }
+
 RT_HD int rt_f2i(float x)
 {
     if (x != x) return 0;
@@ -45,7 +52,6 @@ RT_HD int rt_f2i(float x)
     if (x <= -2147483648.0f) return -2147483647 - 1;
     return (int)x;
 }
-RT_HD float rt_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 
 /* ---- natural logarithm ------------------------------------------------------------
  * x = 2^k * m, m in [sqrt(1/2), sqrt(2)); f = m - 1; s = f / (2 + f); z = s^2.

@@ -219,7 +219,7 @@ __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, 
     p.mode = M_FETCH;
     if (a.partial) {
         float *dst = a.partial + ((size_t)(p.frame_steps & (unsigned)(RT_MAX_BATCH_FRAMES - 1)) * a.partial_plane + pixel) * 3;
-        dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
+        dst[0] = rt_canon_nan(c.x); dst[1] = rt_canon_nan(c.y); dst[2] = rt_canon_nan(c.z);
         return;
     }
     float *dst = a.out + pixel * 3;
@@ -231,7 +231,7 @@ __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, 
 #ifdef RT_COSTMAP
     res = v3(__uint_as_float(RT_COSTMAP == 2 ? p.c_wsteps : p.c_steps), __uint_as_float(p.c_t0), __uint_as_float((unsigned)wall_clock64()));
 #endif
-    dst[0] = res.x; dst[1] = res.y; dst[2] = res.z;
+    dst[0] = rt_canon_nan(res.x); dst[1] = rt_canon_nan(res.y); dst[2] = rt_canon_nan(res.z);
 }
 
 /* the end of a sample (src/raytracer.cu:102-105): add it to the pixel, restart from a copy of the

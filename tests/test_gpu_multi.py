@@ -285,6 +285,12 @@ def test_nan_texture_coordinate_at_a_sphere_pole(rt, orc, ctx, models_dir):
             data = rt.VariableRenderData(W, H)
             rt.render(ctx, scene, rt.Camera(W, H), rt.RenderData(2, 2, True, sky), data, t)
             want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(W, H).floats(), W, H, 2, 2, sky, time_ms=t)
-            a, b = data.previous_render, want
-            same = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))      # a NaN colour (gradient of a NaN u) is a NaN on both sides
-            assert same.all(), (mat[0], t, int((~same).any(axis=2).sum()))
+            assert eq(data.previous_render, want), (mat[0], t)       # bit for bit, NaN pixels included (one canonical NaN)
+    # seed 24964 of the soak: the gradient colour IS the NaN coordinate, so the pixel itself is NaN - on both sides
+    objs = [("sphere", (-0.6021626149655434, 0.5782768403342793, 1.9494934676077007), 0.28375946780666705, ("gradient", 0.11130362971519248))]
+    scene = ctx.commit(rt.SceneObjects(objs))
+    data = rt.VariableRenderData(128, 72)
+    rt.render(ctx, scene, rt.Camera(128, 72), rt.RenderData(4, 4, True, (0.0, 0.0, 0.0)), data, 24965)
+    want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(128, 72).floats(), 128, 72, 4, 4, (0.0, 0.0, 0.0), time_ms=24965)
+    assert np.isnan(want).sum() >= 1 and eq(data.previous_render, want)
+    assert (data.previous_render.view(np.uint32)[np.isnan(data.previous_render)] == 0x7fc00000).all()

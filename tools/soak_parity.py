@@ -9,14 +9,28 @@ rt = importlib.import_module("ray-tracer_amd")
 from oracle import binding as orc
 from test_gpu_parity import _random_scene
 first, count = int(sys.argv[1]), int(sys.argv[2])
+mode = sys.argv[3] if len(sys.argv) > 3 else "random"      # "random": random mixed scenes; "config": the config / reference scenes from random cameras
 ctx = rt.Context(0)
 md = rt.scenes.models_dir()
 bad = 0
+names = ["monkey", "cube", "reference_scene0", "reference_scene1", "reference_scene2", "reference_scene3", "reference_scene4", "three_sphere"]
+committed = {}
 for seed in range(first, first + count):
-    objs, sky = _random_scene(seed)
     W, H, spp, limit = 96 + 8 * (seed % 5), 64 + 8 * (seed % 3), 3 + seed % 3, 2 + seed % 7
-    cam = rt.Camera(W, H)
-    scene = ctx.commit(rt.SceneObjects(objs))
+    if mode == "config":
+        name = names[seed % len(names)]
+        objs, sky = rt.scenes.CONFIG_SCENES[name]()
+        rng = np.random.default_rng(seed)
+        # a camera somewhere in front of / inside the scene, looking roughly at it
+        pos = tuple(float(x) for x in rng.uniform([-0.6, -0.3, -0.5], [0.6, 0.6, 0.8]))
+        cam = rt.Camera(W, H, pos=pos, fov=float(rng.uniform(0.6, 1.4)), focal_len=0.1, rot=tuple(float(x) for x in rng.uniform(-0.35, 0.35, 3)))
+        if name not in committed:
+            committed[name] = ctx.commit(rt.SceneObjects(objs))
+        scene = committed[name]
+    else:
+        objs, sky = _random_scene(seed)
+        cam = rt.Camera(W, H)
+        scene = ctx.commit(rt.SceneObjects(objs))
     o = orc.Scene(objs, orc.MATH_DET, md)
     want1 = o.render(cam.floats(), W, H, spp, limit, sky, time_ms=seed)
     want = want1
