@@ -17,6 +17,8 @@ names = ["monkey", "cube", "reference_scene0", "reference_scene1", "reference_sc
 committed = {}
 for seed in range(first, first + count):
     W, H, spp, limit = 96 + 8 * (seed % 5), 64 + 8 * (seed % 3), 3 + seed % 3, 2 + seed % 7
+    if os.environ.get("RT_SOAK_SIZE"):                      # e.g. 640x360x32: bigger frames, more samples per pixel
+        W, H, spp = [int(x) for x in os.environ["RT_SOAK_SIZE"].split("x")]
     if mode == "config":
         name = names[seed % len(names)]
         objs, sky = rt.scenes.CONFIG_SCENES[name]()
