@@ -9,7 +9,7 @@ rt = importlib.import_module("ray-tracer_amd")
 from oracle import binding as orc
 from test_gpu_parity import _random_scene
 first, count = int(sys.argv[1]), int(sys.argv[2])
-mode = sys.argv[3] if len(sys.argv) > 3 else "random"      # "random": random mixed scenes; "config": the config / reference scenes from random cameras
+mode = sys.argv[3] if len(sys.argv) > 3 else "random"      # "random": random mixed scenes; "config": the config / reference scenes from random cameras; "bigmesh": triangle soups
 ctx = rt.Context(0)
 md = rt.scenes.models_dir()
 bad = 0
@@ -29,6 +29,23 @@ for seed in range(first, first + count):
         if name not in committed:
             committed[name] = ctx.commit(rt.SceneObjects(objs))
         scene = committed[name]
+    elif mode == "bigmesh":
+        # one or two random triangle soups of 100..3,000 triangles (leaves of the fixed-depth-10 tree then hold several
+        # triangles; the larger ones do not fit LDS and run the global-memory variant) + spheres
+        rng = np.random.default_rng(seed)
+        objs = []
+        for _ in range(int(rng.integers(1, 3))):
+            n = int(rng.integers(100, 3000))
+            c = rng.uniform([-0.8, -0.5, 1.4], [0.8, 0.6, 3.0])
+            tris = (c + rng.normal(0, 0.35, (n, 1, 3)) + rng.normal(0, 0.06, (n, 3, 3))).astype(np.float32).reshape(n, 9)
+            mat = ("standard", tuple(float(x) for x in rng.uniform(0.2, 1, 3)), float(rng.uniform(0, 0.6))) if rng.integers(0, 3) else ("refractive", (1.0, 1.0, 1.0), 1.5)
+            objs.append(("mesh", tris, mat))
+        objs.append(("sphere", (0, 1.3, 1.5), 0.5, ("emissive", (1, 1, 1), 5.0)))
+        if rng.integers(0, 2):
+            objs.append(("sphere", (0, -100.5, 1.5), 100, ("standard", (0.5, 0.5, 0.5), 0.2)))
+        sky = (0.8, 1.0, 1.0) if rng.integers(0, 2) else (0.0, 0.0, 0.0)
+        cam = rt.Camera(W, H)
+        scene = ctx.commit(rt.SceneObjects(objs))
     else:
         objs, sky = _random_scene(seed)
         cam = rt.Camera(W, H)
