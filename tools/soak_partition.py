@@ -1,0 +1,58 @@
+"""Partition soak (development tool, GPU only - no oracle): random scenes, image sizes, rank counts, band heights and
+frame counts; the multi-GPU entry points (several contexts on this GPU standing in for several GPUs:
+rt_render_multi_device over two calls, and rt_render_device_batch + rt_gather by hand) must reproduce the
+single-context frame bit for bit.   python tools/soak_partition.py <first seed> <count>"""
+import importlib, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+rt = importlib.import_module("ray-tracer_amd")
+from test_gpu_parity import _random_scene
+first, count = int(sys.argv[1]), int(sys.argv[2])
+ctxs = [rt.Context(0) for _ in range(6)]
+names = ["monkey", "cube", "reference_scene0", "three_sphere"]
+bad = 0
+side = torch.cuda.Stream()
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    if seed % 3 == 0:
+        objs, sky = rt.scenes.CONFIG_SCENES[names[(seed // 3) % len(names)]]()
+    else:
+        objs, sky = _random_scene(seed)
+    W, H = int(rng.integers(1, 200)), int(rng.integers(1, 150))
+    n = int(rng.integers(1, 7))
+    band_rows = int(rng.choice([8, 8, 16, 24]))
+    f1, f2 = int(rng.integers(1, 5)), int(rng.integers(0, 4))
+    spp, limit = int(rng.integers(1, 4)), int(rng.integers(1, 7))
+    cam, rd = rt.Camera(W, H), rt.RenderData(spp, limit, True, sky)
+    so = rt.SceneObjects(objs)
+    scenes = [c.commit(so) for c in ctxs[:n]]
+    times = [int(x) for x in rng.integers(-2**31, 2**31 - 1, f1 + f2)]
+    ref = rt.VariableRenderData(W, H)
+    rt.render_frames(ctxs[0], scenes[0], cam, rd, ref, times)
+    frame = torch.full((H, W, 3), -1.0, device="cuda:0")
+    torch.cuda.synchronize()
+    stream = side.cuda_stream if seed % 2 else None
+    rt.render_multi_device(ctxs[:n], scenes, cam, rd, times[:f1], 0, frame.data_ptr(), band_rows=band_rows, stream=stream)
+    if f2:
+        rt.render_multi_device(ctxs[:n], scenes, cam, rd, times[f1:], f1, frame.data_ptr(), band_rows=band_rows, stream=stream)
+    torch.cuda.synchronize()
+    ok = np.array_equal(frame.cpu().numpy().view(np.uint32), ref.previous_render.view(np.uint32))
+    # by hand: compact launches + rt_gather
+    out = torch.full((H, W, 3), -1.0, device="cuda:0")
+    bufs = []
+    for r in range(n):
+        rows = rt.tile_owned_rows(H, band_rows, r, n)
+        buf = torch.zeros((max(rows, 1), W, 3), device="cuda:0")
+        bufs.append(buf)
+        if rows:
+            rt.render_device_batch(ctxs[r], scenes[r], cam, rd, times, 0, buf.data_ptr(), band_rows=band_rows, band_first=r, band_stride=n, compact=True, stream=stream)
+            rt.gather(ctxs[0], out.data_ptr(), W, H, ctxs[r], buf.data_ptr(), band_rows, r, n, stream=stream)
+    torch.cuda.synchronize()
+    ok = ok and np.array_equal(out.cpu().numpy().view(np.uint32), ref.previous_render.view(np.uint32))
+    if not ok:
+        bad += 1
+        print("MISMATCH seed", seed, "WxH", W, H, "ranks", n, "band_rows", band_rows, "frames", f1, f2, flush=True)
+print("partition soak: %d cases, %d mismatches" % (count, bad), flush=True)
+sys.exit(1 if bad else 0)
