@@ -187,3 +187,53 @@ def test_tile_owned_rows(rt):
     assert sum(rt.tile_owned_rows(1080, 8, r, 8) for r in range(8)) == 1080
     assert rt.tile_owned_rows(203, 8, 1, 2) == 13 * 8        # 26 bands (last one ragged), 13 each
     assert rt.tile_owned_rows(100, 8, 2, 2) == -1             # band_first out of range
+
+
+def test_obj_loader_fuzz_against_the_oracle(rt, orc, tmp_path):
+    """200 random .obj texts - number formats (fixed, exponent, signs, no leading zero), triangle and quad faces as bare
+    indices or i/j/k, comments / vn / vt / o / s / usemtl lines, empty lines, a missing final newline - through the
+    product's loader (rt_obj_load) and the oracle's restatement of ObjFileMesh (src/obj_read.cu:47-147), then through
+    random enlarge / rotate / translate: vertices, face arities and the quad-split triangle list must agree bit for bit."""
+    rng = np.random.default_rng(2024)
+
+    def num(x):
+        k = rng.integers(0, 5)
+        if k == 0:
+            return "%.6f" % x
+        if k == 1:
+            return "%.3e" % x
+        if k == 2:
+            return repr(float(np.float32(x)))
+        if k == 3:
+            return ("%.4f" % x).replace("0.", ".", 1) if abs(x) < 1 else "%.2f" % x
+        return "%d" % int(x)
+
+    for case in range(200):
+        nv = int(rng.integers(3, 40))
+        lines = ["# fuzz %d" % case, "mtllib nothing.mtl", "o thing"]
+        for _ in range(nv):
+            x, y, z = rng.uniform(-3, 3, 3)
+            lines.append("v %s %s %s" % (num(x), num(y), num(z)))
+            if rng.integers(0, 4) == 0:
+                lines.append(rng.choice(["vn 0 1 0", "vt 0.5 0.25", "", "s off", "usemtl m"]))
+        for _ in range(int(rng.integers(1, 30))):
+            idx = rng.choice(nv, min(nv, int(rng.choice([3, 3, 4]))), replace=False) + 1
+            style = rng.integers(0, 3)
+            toks = ["%d" % i if style == 0 else ("%d/%d/%d" % (i, rng.integers(1, 9), rng.integers(1, 9)) if style == 1 else "%d//%d" % (i, rng.integers(1, 9))) for i in idx]
+            lines.append("f " + " ".join(toks))
+        text = "\n".join(lines) + ("\n" if rng.integers(0, 2) else "")
+        p = tmp_path / ("f%d.obj" % case)
+        p.write_text(text)
+        a, b = rt.ObjFileMesh(str(p)), orc.Obj(str(p), orc.MATH_DET)
+        steps = []
+        for _ in range(int(rng.integers(0, 4))):
+            k = rng.integers(0, 3)
+            steps.append(("enlarge", float(rng.uniform(0.1, 3))) if k == 0 else
+                         ("rotate",) + tuple(float(v) for v in rng.uniform(-7, 7, 3)) if k == 1 else
+                         ("translate",) + tuple(float(v) for v in rng.uniform(-5, 5, 3)))
+        for s in steps:
+            getattr(a, s[0])(*s[1:])
+            getattr(b, s[0])(*s[1:])
+        assert a.num_vertices == b.num_vertices and a.face_arities() == b.face_arities(), case
+        assert np.array_equal(a.vertices().view(np.uint32), b.vertices().view(np.uint32)), (case, steps)
+        assert np.array_equal(a.triangles().view(np.uint32), b.triangles().view(np.uint32)), (case, steps)
