@@ -66,5 +66,7 @@ for seed in range(first, first + count):
     if not ok:
         bad += 1
         print("MISMATCH seed", seed, flush=True)
+    if (seed - first + 1) % 500 == 0:
+        print("... %d scenes, %d mismatches so far" % (seed - first + 1, bad), flush=True)     # a long run must not look hung
 print("soak: %d scenes, %d mismatches" % (count, bad), flush=True)
 sys.exit(1 if bad else 0)

@@ -54,5 +54,7 @@ for seed in range(first, first + count):
     if not ok:
         bad += 1
         print("MISMATCH seed", seed, "WxH", W, H, "ranks", n, "band_rows", band_rows, "frames", f1, f2, flush=True)
+    if (seed - first + 1) % 1000 == 0:
+        print("... %d cases, %d mismatches so far" % (seed - first + 1, bad), flush=True)
 print("partition soak: %d cases, %d mismatches" % (count, bad), flush=True)
 sys.exit(1 if bad else 0)
