@@ -38,7 +38,7 @@ RT_HD float rt_u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f;
  * x86 returns INT_MIN for them, so a plain cast would make the CPU oracle and the GPU disagree exactly where the
  * reference's texture lookups (src/material.cu:90-99, :119-124) and display conversion (src/main.cu:343-371) can
  * meet such a value: a sphere's texture u is asin((P.y - c.y) / r), and at the pole that quotient exceeds 1 by an
- * ulp now and then -> NaN.  (Found by tools/soak_parity.py: one pixel in 3,000 random scenes.) */
+ * ulp now and then -> NaN.  (Found by tests/soak/soak_parity.py: one pixel in 3,000 random scenes.) */
 /* A NaN that reaches the frame buffer is stored as THE quiet NaN 0x7fc00000.  The reference can produce one (a
  * GRADIENT-textured sphere hit at its pole: the texture colour is the NaN u or v itself, src/material.cu:80-82) and
  * leaves its sign and payload to the platform - x86 and gfx950 already differ in the NaN that 0/0 gives - so

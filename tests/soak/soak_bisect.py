@@ -1,8 +1,8 @@
-"""Shrinks a mismatching soak scene (development tool): drops objects one at a time while the HIP frame still differs
-from the oracle.   python tools/soak_bisect.py <seed> <time_ms> <spp> <limit>"""
+"""Shrinks a mismatching soak scene (test infrastructure, run by hand on the GPU box): drops objects one at a time while the HIP frame still differs
+from the oracle.   python tests/soak/soak_bisect.py <seed> <time_ms> <spp> <limit>"""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 rt = importlib.import_module("ray-tracer_amd")
 from oracle import binding as orc

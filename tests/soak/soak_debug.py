@@ -1,7 +1,7 @@
-"""Details of one soak seed (development tool): python tools/soak_debug.py <seed>"""
+"""Details of one soak seed (test infrastructure, run by hand on the GPU box): python tests/soak/soak_debug.py <seed>"""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 rt = importlib.import_module("ray-tracer_amd")
 from oracle import binding as orc

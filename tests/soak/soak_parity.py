@@ -1,9 +1,9 @@
-"""One-off parity soak (development tool): many seeded random mixed scenes (tests/test_gpu_parity.py::_random_scene),
+"""One-off parity soak (test infrastructure, run by hand on the GPU box): many seeded random mixed scenes (tests/test_gpu_parity.py::_random_scene),
 each rendered by a one-frame launch and by a three-frame launch (twice: the second runs on the measured-cost
-schedule), against the CPU oracle, bit for bit.   python tools/soak_parity.py <first seed> <count>"""
+schedule), against the CPU oracle, bit for bit.   python tests/soak/soak_parity.py <first seed> <count>"""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 rt = importlib.import_module("ray-tracer_amd")
 from oracle import binding as orc

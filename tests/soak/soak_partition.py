@@ -1,11 +1,11 @@
 """Partition soak (development tool, GPU only - no oracle): random scenes, image sizes, rank counts, band heights and
 frame counts; the multi-GPU entry points (several contexts on this GPU standing in for several GPUs:
 rt_render_multi_device over two calls, and rt_render_device_batch + rt_gather by hand) must reproduce the
-single-context frame bit for bit.   python tools/soak_partition.py <first seed> <count>"""
+single-context frame bit for bit.   python tests/soak/soak_partition.py <first seed> <count>"""
 import importlib, os, sys
 import numpy as np
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 rt = importlib.import_module("ray-tracer_amd")
 from test_gpu_parity import _random_scene

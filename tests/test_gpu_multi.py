@@ -269,7 +269,7 @@ def test_more_frames_than_one_launch_holds(rt, orc, models_dir):
 
 
 def test_nan_texture_coordinate_at_a_sphere_pole(rt, orc, ctx, models_dir):
-    """Found by tools/soak_parity.py (seed 7895, one pixel in 3,000 random scenes): at a sphere's pole
+    """Found by tests/soak/soak_parity.py (seed 7895, one pixel in 3,000 random scenes): at a sphere's pole
     (P.y - c.y) / r can exceed 1 by an ulp, asin gives NaN, and the image / checkerboard lookups convert a NaN u to
     int - undefined in C (x86: INT_MIN), 0 on CUDA and on gfx950.  rt_math.h's rt_f2i defines it (NaN -> 0,
     saturating) for the oracle and the kernel alike; this is the scene and the pixel that differed."""
