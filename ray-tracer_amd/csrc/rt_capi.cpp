@@ -904,7 +904,9 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
             (void)hipGetLastError();
         }
     }
-    /* the image so far goes out to its owners */
+    /* the image so far goes out to its owners.  (root->ev_multi is recorded twice in this function: here, on the
+     * caller's stream, as "the ranks may start", and further down on rank 0's stream as "rank 0's bands are in the
+     * staging area"; a hipStreamWaitEvent captures the record that precedes it, and the calls are in that order.) */
     if (frame_num > 0) {
         RT_HIP(root, hipSetDevice(root->device), "selecting device");
         for (int i = 0; i < n_ranks; i++) RT_HIP(root, copy_bands(L, i, d_frame, root->d_stage + off[i], false, s0), "interleaving bands");
