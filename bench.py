@@ -20,19 +20,31 @@ Workloads (--config, BASELINE.json configs[i]; --scene/--width/--height/--spp/--
     3  models/low_poly_monkey.obj + emissive sphere light, 1920x1080, 1024 spp, 8 bounces   (default: the
        configuration the metric and the north-star target are quoted on)
     4  the monkey scene, 3840x2160, 4096 spp, 8 bounces (the 8-GPU configuration; runs on any N)
+    ref0  the reference's own default workload (src/main.cu:11, 318-330, src/camera.cu:4-5): its scene 0
+       (Cornell box + monkey + mirror sphere), 1000x800, 100 spp x 5 bounces per frame - the only workload the
+       reference prints a number for (FPS, src/main.cu:423-428); the line carries "frames_per_s" beside Msamples/s
+    --scene soup6k | sphere50k: meshes beyond a CU's LDS (6,000 random triangles; a 50,880-triangle surface)
 
-N GPUs.  One process per GPU; every rank renders the 8-row bands it owns (band b belongs to rank b % N)
-of every frame into a compact HBM buffer, one gather (RCCL over xGMI) brings the bands to rank 0, which
-de-interleaves them.  The headline for every N is STRONG scaling of the configured image (1920x1080 for
+N GPUs.  One process per GPU.  Every rank owns a list of 8x8 tiles of the image: the warm-up launch runs on an
+interleaved ownership and measures what every tile costs, the costs are summed over the ranks (one small
+all-reduce), every rank computes the same longest-processing-time-first ownership (rt_partition_tiles), and
+the timed launches run on it; one gather (RCCL over xGMI) brings every rank's tiles to rank 0, which puts
+them into the frame (rt_tiles_copy_device).  (--partition bands: round 2's static partition, band b of 8 rows
+belongs to rank b % N.)  The headline for every N is STRONG scaling of the configured image (1920x1080 for
 the metric): K frames cut over N GPUs, each rank rendering its share of all K frames in one launch.  A
 single 1080p frame cannot scale (a pixel's 1024 samples are one sequential random stream and the most
 expensive tile alone takes ~95 % of a one-GPU frame), a sequence of frames can: each GPU
 overlaps its K x tiles/N tile-frames.  For N > 1 the line also carries, as extras, the weak-scaling
-measurement (image area grows with N at fixed aspect and field of view) and BASELINE configs[4]
-(3840x2160, 4096 spp).  When WORLD_SIZE is not set and N > 1 this script starts its own N ranks
-(torch.distributed.run) before touching the GPU and relays rank 0's line.
+measurement (image area grows with N at fixed aspect and field of view), BASELINE configs[4]
+(3840x2160, 4096 spp) and "capi_multi": the same K frames through rt_render_multi_device - the C ABI's
+one-host-thread path a C++ maintainer of the reference would call - from rank 0 over all visible GPUs,
+timed, with the peer-access status of every GPU pair and a bit-equality check against the gathered frame.
+When WORLD_SIZE is not set and N > 1 this script starts its own N ranks (torch.distributed.run) before
+touching the GPU and relays rank 0's line.  If RCCL cannot initialise the run FAILS (exit code 3) unless
+--allow-gloo-fallback is given.
 
 Besides the contract's keys the JSON line carries
+  backend, world_size   the process group that moved the tiles ("none" for N = 1)
   roofline      the render kernel against the HBM roof (algorithmic bytes: 24 B per pixel per frame + the
                 scene once), with the rocprofv3-measured HBM bytes of the same launch
                 shape (profiles/traffic.json) and the GB/s they amount to - honest reading: this
@@ -40,7 +52,8 @@ Besides the contract's keys the JSON line carries
   valu          the same kernel against the FP32 vector peak, with algorithmic FLOPs per sample from
                 the counting rule of SURVEY.md §8(d) applied to the oracle's counters;
   cpu_baseline  the CPU oracle (a port of the reference's algorithm, oracle/) timed on this box's host
-                cores on a bounded sample of the same workload (rank 0, N=1 only), all cores and one.
+                cores on a bounded sample of the same workload (rank 0, N=1 only): on the 16-thread share
+                of a one-GPU box, on all host threads ("all_threads") and on one.
 """
 import argparse
 import json
@@ -55,34 +68,48 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3
-MAX_BATCH = 32                 # RT_MAX_BATCH_FRAMES
+MAX_BATCH = 32                 # RT_MAX_BATCH_FRAMES (rt_max_batch_frames lowers it for images whose planes would not fit)
 
 CONFIGS = {1: ("three_sphere", 1920, 1080, 1024, 8), 2: ("cube", 1920, 1080, 1024, 8),
-           3: ("monkey", 1920, 1080, 1024, 8), 4: ("monkey", 3840, 2160, 4096, 8)}
+           3: ("monkey", 1920, 1080, 1024, 8), 4: ("monkey", 3840, 2160, 4096, 8),
+           "ref0": ("reference_scene0", 1000, 800, 100, 5)}
+SCENES = ["three_sphere", "cube", "monkey", "reference_scene0", "reference_scene1", "reference_scene3", "soup6k", "sphere50k"]
+EXIT_NO_RCCL = 3
 
 
-def parse_args():
+def config_key(s):
+    return s if s == "ref0" else int(s)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS), help="BASELINE.json configs[i] (default 3: the metric's configuration)")
-    ap.add_argument("--scene", default=None, choices=["three_sphere", "cube", "monkey"])
+    ap.add_argument("--config", type=config_key, default=3, choices=[1, 2, 3, 4, "ref0"],
+                    help="BASELINE.json configs[i] (default 3: the metric's configuration), or ref0: the reference's own default workload")
+    ap.add_argument("--scene", default=None, choices=SCENES)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--limit", type=int, default=None)
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the same WxH frames for every N (default, the metric's 1920x1080), weak = image area grows with N")
-    ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the weak-scaling and configs[4] side measurements")
+    ap.add_argument("--partition", default="lists", choices=["lists", "bands"],
+                    help="N > 1: lists = cost-balanced tile lists (default), bands = round 2's static bands (band b -> rank b %% N)")
+    ap.add_argument("--no-extras", action="store_true", help="N > 1: skip the weak-scaling, configs[4] and capi_multi side measurements")
+    ap.add_argument("--capi-multi", default=None, metavar="DEVICES",
+                    help="also time rt_render_multi_device from ONE process over these devices (e.g. 0,0 rehearses two ranks on one GPU); "
+                         "N > 1 does it over all visible GPUs unless --no-extras")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frame-by-frame", action="store_true", help="one launch + one gather per step instead of multi-frame launches")
     ap.add_argument("--no-frame-by-frame-leg", action="store_true", help="skip the extra one-launch-per-step measurement (keeps a profile's launches all of one kind)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo + --share-gpu rehearses N ranks on ONE GPU (RCCL refuses duplicate devices)")
+    ap.add_argument("--allow-gloo-fallback", action="store_true", help="if RCCL cannot initialise, measure through gloo + host memory instead of failing")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the frames alone and checks the gathered frame equals it bit for bit")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     scene, W, H, spp, limit = CONFIGS[args.config]
     args.scene = args.scene or scene
     args.width = args.width or W
@@ -132,22 +159,36 @@ def cpu_model():
 
 def cpu_baseline(rt, objs, sky, W, H, limit, spp_full, budget_s=12.0):
     """The oracle (det mode) on a bounded sample of the workload: the full frame at a reduced spp (per-sample
-    work does not depend on spp), on all host threads available to this process and on one."""
+    work does not depend on spp).  Three figures: on the 16-thread CPU share of a one-GPU box (the headline
+    `value`; RT_BENCH_CPU_THREADS overrides), on ALL host threads available to this process ("all_threads",
+    what SURVEY.md §8(d) asks for), and on one thread."""
     from oracle import binding as B
     B.build()
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # a one-GPU box's CPU share is 16 cores; RT_BENCH_CPU_THREADS overrides
     threads = int(os.environ.get("RT_BENCH_CPU_THREADS", min(avail, 16)))
     sc = B.Scene(objs, B.MATH_DET, rt.scenes.models_dir())
     cam = rt.Camera(W, H).floats()
-    t = time.perf_counter()
-    sc.render(cam, W, H, 1, limit, sky, nthreads=threads)
-    probe = time.perf_counter() - t
-    spp = int(max(1, min(spp_full, budget_s / max(probe, 1e-3))))
-    t = time.perf_counter()
-    _, st = sc.render(cam, W, H, spp, limit, sky, nthreads=threads, with_stats=True)
-    dt = time.perf_counter() - t
-    value = W * H * spp / dt / 1e6
+
+    def timed(nthreads, budget):
+        t = time.perf_counter()
+        sc.render(cam, W, H, 1, limit, sky, nthreads=nthreads)
+        probe = time.perf_counter() - t
+        spp = int(max(1, min(spp_full, budget / max(probe, 1e-3))))
+        t = time.perf_counter()
+        _, st = sc.render(cam, W, H, spp, limit, sky, nthreads=nthreads, with_stats=True)
+        dt = time.perf_counter() - t
+        return W * H * spp / dt / 1e6, spp, dt, st
+
+    value, spp, dt, st = timed(threads, budget_s)
+    out = {"value": value, "unit": "Msamples/s", "cores": threads, "kind": "port",
+           "sample": "%dx%d full frame at %d spp of %d, %d bounces, %.1f s" % (W, H, spp, spp_full, limit, dt),
+           "cpu_model": cpu_model(), "host_threads_available": avail}
+    if avail > threads:
+        v_all, spp_all, dt_all, _ = timed(avail, budget_s)
+        out["all_threads"] = {"value": v_all, "unit": "Msamples/s", "cores": avail,
+                              "sample": "%dx%d full frame at %d spp of %d, %d bounces, %.1f s" % (W, H, spp_all, spp_full, limit, dt_all)}
+    else:
+        out["all_threads"] = {"value": value, "unit": "Msamples/s", "cores": threads, "sample": "the figure above: this process has no more threads"}
     # one thread: a band of rows through the middle of the image (where the geometry is), ~4 s
     rows = max(8, min(H, int(4.0 * value * 1e6 / threads / W) // 8 * 8))
     y0 = max(0, (H - rows) // 2) // 8 * 8
@@ -159,12 +200,39 @@ def cpu_baseline(rt, objs, sky, W, H, limit, spp_full, budget_s=12.0):
     sc.render(cam, W, H, 1, limit, sky, nthreads=threads, y0=y0, y1=y0 + rows)
     dtn = time.perf_counter() - t
     single = value * dtn / dt1 if dt1 > 0 else None
-    return {"value": value, "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": "%dx%d full frame at %d spp of %d, %d bounces, %.1f s" % (W, H, spp, spp_full, limit, dt),
-            "cpu_model": cpu_model(), "host_threads_available": avail,
-            "single_thread": {"value": single, "unit": "Msamples/s", "cores": 1,
-                              "sample": "rows %d..%d at 1 spp on one thread (%.1f s) against the same rows on %d threads (%.2f s), "
-                                        "applied to the all-thread figure" % (y0, y0 + rows, dt1, threads, dtn)}}, st
+    out["single_thread"] = {"value": single, "unit": "Msamples/s", "cores": 1,
+                            "sample": "rows %d..%d at 1 spp on one thread (%.1f s) against the same rows on %d threads (%.2f s), "
+                                      "applied to the %d-thread figure" % (y0, y0 + rows, dt1, threads, dtn, threads)}
+    return out, st
+
+
+def init_process_group(args, dev, world):
+    """-> (backend actually used, note or None).  A failed RCCL initialisation ends the run with EXIT_NO_RCCL unless
+    --allow-gloo-fallback: a gloo line must never be mistaken for an xGMI measurement."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.backend == "gloo":
+        dist.init_process_group("gloo")
+        return "gloo", None
+    try:
+        dist.init_process_group("nccl", device_id=dev)
+        probe = torch.zeros(1, device=dev)
+        dist.all_reduce(probe)                      # RCCL builds its communicator here, not at init
+        torch.cuda.synchronize()
+        return "nccl", None
+    except Exception as e:                          # noqa: BLE001
+        msg = "nccl (RCCL) failed to initialise (%s: %s)" % (type(e).__name__, str(e)[:300])
+        if not args.allow_gloo_fallback:
+            sys.stderr.write("bench.py: %s; --allow-gloo-fallback measures through gloo and host memory instead\n" % msg)
+            sys.stderr.flush()
+            os._exit(EXIT_NO_RCCL)                  # every rank fails the same way; no half-initialised group to tear down
+        try:
+            dist.destroy_process_group()
+        except Exception:                           # noqa: BLE001
+            pass
+        dist.init_process_group("gloo")
+        return "gloo", msg + "; the gather went through gloo and host memory"
 
 
 def main():
@@ -173,6 +241,7 @@ def main():
         spawn_ranks(args.gpus)
 
     import importlib
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -189,25 +258,12 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible); --share-gpu --backend gloo rehearses on one" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    backend_note = None
+    backend, backend_note = "none", None
+    host_group = None
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=dev)
-                probe = torch.zeros(1, device=dev)
-                dist.all_reduce(probe)                      # RCCL builds its communicator here, not at init
-                torch.cuda.synchronize()
-            except Exception as e:                          # noqa: BLE001  (a measurement beats no measurement: say so in the line)
-                backend_note = "nccl (RCCL) failed to initialise (%s: %s); the gather went through gloo and host memory" % (type(e).__name__, str(e)[:200])
-                try:
-                    dist.destroy_process_group()
-                except Exception:                           # noqa: BLE001
-                    pass
-                args.backend = "gloo"
-                dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("gloo")
+        backend, backend_note = init_process_group(args, dev, world)
+        # a host-side group for waiting without occupying the GPU (an RCCL barrier is a kernel that spins on every rank's GPU)
+        host_group = dist.new_group(backend="gloo") if backend != "gloo" else None
 
     rt = importlib.import_module("ray-tracer_amd")
     dm = importlib.import_module("ray-tracer_amd.distributed")
@@ -218,6 +274,7 @@ def main():
     info = scene.info()
     band_rows = 8
     stream = torch.cuda.current_stream().cuda_stream
+    use_lists = world > 1 and args.partition == "lists"
 
     def fence():
         if world > 1:
@@ -227,89 +284,131 @@ def main():
     def measure(W, H, spp, limit, warmup, steps, batched):
         """`warmup` untimed + `steps` timed steps on a W x H image over all ranks.  batched: the steps are
         consecutive progressive frames (frame_num 0, 1, ...; seeds 12345 + i) rendered by multi-frame
-        launches (rt_render_device_batch, at most MAX_BATCH frames per launch, launches of equal size) and
-        gathered once at the end; otherwise one launch + one gather per step (each an independent frame 0).
-        Returns the wall time (max over ranks), rank 0's gathered frame, this rank's per-launch kernel times
-        and how many frames each of those launches rendered."""
+        launches (rt_render_device_batch, launches of equal size) and gathered once at the end; otherwise one
+        launch + one gather per step (each an independent frame 0).  Tile lists: the warm-up runs on the
+        interleaved ownership (at least one frame: it is what measures the tiles), then the ranks agree on the
+        cost-balanced ownership.  Returns a dict: the wall time (max over ranks), rank 0's gathered frame, this
+        rank's per-launch kernel times and frames per launch, its pixels, the partition."""
         cam = rt.Camera(W, H)
         rd = rt.RenderData(spp, limit, True, sky)
-        local = torch.zeros((dm.max_owned_rows(H, band_rows, world), W, 3), dtype=torch.float32, device=dev)
-        gathered = torch.empty((world,) + tuple(local.shape), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+        max_batch = min(MAX_BATCH, ctx.max_batch_frames(W, H))
         kernel_ms, frames_per_launch = [], []
+        part = {"kind": "tile lists (cost-balanced)" if use_lists else "bands of 8 rows"}
 
-        def run(n, record):
+        def run(n, record, lists, hints, local, gathered):
+            spec = dict(tile_list=lists[rank], tile_cost=hints, compact=True) if lists is not None else dict(band_first=rank, band_stride=world, compact=True)
+
+            def collect():
+                if lists is not None:
+                    return dm.gather_tiles(local, lists, W, H, rank, world, ctx=ctx, dst=0, out=gathered, stream=stream)
+                return dm.gather_frame(local, W, H, band_rows, rank, world, dst=0, out=gathered)
             if batched:
-                launches = (n + MAX_BATCH - 1) // MAX_BATCH
+                launches = (n + max_batch - 1) // max_batch
                 done = 0
                 for i in range(launches):
                     k = (n - done + (launches - i) - 1) // (launches - i)
-                    rt.render_device_batch(ctx, scene, cam, rd, [12345 + done + j for j in range(k)], done, local.data_ptr(),
-                                           band_first=rank, band_stride=world, compact=True, stream=stream)
+                    rt.render_device_batch(ctx, scene, cam, rd, [12345 + done + j for j in range(k)], done, local.data_ptr(), stream=stream, **spec)
                     if record:
                         kernel_ms.append(ctx.last_kernel_ms())   # HIP events on the launch stream; waits for the kernel only
                         frames_per_launch.append(k)
                     done += k
-                return dm.gather_frame(local, W, H, band_rows, rank, world, dst=0, out=gathered)
+                return collect()
             frame = None
             for _ in range(n):
-                rt.render_device(ctx, scene, cam, rd, 12345, 0, local.data_ptr(), band_first=rank, band_stride=world, compact=True, stream=stream)
-                frame = dm.gather_frame(local, W, H, band_rows, rank, world, dst=0, out=gathered)
+                rt.render_device(ctx, scene, cam, rd, 12345, 0, local.data_ptr(), stream=stream, **spec)
+                frame = collect()
                 if record:
                     kernel_ms.append(ctx.last_kernel_ms())
                     frames_per_launch.append(1)
             return frame
 
-        if warmup > 0:
-            run(warmup, False)
+        def buffers(lists):
+            if lists is not None:
+                local = torch.zeros(dm.compact_floats(lists), dtype=torch.float32, device=dev)
+            else:
+                local = torch.zeros((dm.max_owned_rows(H, band_rows, world), W, 3), dtype=torch.float32, device=dev)
+            gathered = torch.empty((world,) + tuple(local.shape), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+            return local, gathered
+
+        lists = hints = None
+        if use_lists:
+            lists0 = dm.tile_lists(dm.initial_ownership(W, H, world), world)
+            local, gathered = buffers(lists0)
+            run(max(warmup, 1), False, lists0, None, local, gathered)
+            owner, cost = dm.balanced_ownership(ctx, W, H, lists0, rank, world, device=dev)
+            lists = dm.tile_lists(owner, world)
+            hints = cost[lists[rank]]
+            loads = [int(cost[l].astype(np.int64).sum()) for l in lists]
+            part.update({"tiles_per_rank": [int(len(l)) for l in lists], "cost_share_per_rank": [round(x / float(max(1, sum(loads))), 4) for x in loads]})
+            local, gathered = buffers(lists)
+            my_pixels = sum(min(8, W - (int(g) % ((W + 7) // 8)) * 8) * min(8, H - (int(g) // ((W + 7) // 8)) * 8) for g in lists[rank])
+        else:
+            local, gathered = buffers(None)
+            if warmup > 0:
+                run(warmup, False, None, None, local, gathered)
+            my_pixels = sum((min((b + 1) * band_rows, H) - b * band_rows) * W for b in dm.owned_bands(H, band_rows, rank, world))
         fence()
         t0 = time.perf_counter()
-        frame = run(steps, True)
+        frame = run(steps, True, lists, hints, local, gathered)
         fence()
         elapsed = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            if args.backend == "gloo":
+            if backend == "gloo":
                 t = t.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        return elapsed, frame, kernel_ms, frames_per_launch, cam, rd
+        return {"elapsed": elapsed, "frame": frame, "kernel_ms": kernel_ms, "frames_per_launch": frames_per_launch, "cam": cam, "rd": rd,
+                "my_pixels": my_pixels, "partition": part}
 
     W, H, spp, limit = args.width, args.height, args.spp, args.limit
     if world > 1 and args.scaling == "weak":
         W, H = weak_image(args.width, args.height, world)
     batched = not args.frame_by_frame
-    elapsed, frame, kernel_ms, frames_per_launch, cam, rd = measure(W, H, spp, limit, args.warmup, args.steps, batched)
+    m = measure(W, H, spp, limit, args.warmup, args.steps, batched)
+    elapsed, frame, kernel_ms, frames_per_launch, cam, rd = m["elapsed"], m["frame"], m["kernel_ms"], m["frames_per_launch"], m["cam"], m["rd"]
     per_frame = None
     if batched and rank == 0 and world == 1 and not args.no_frame_by_frame_leg:
         # for the record: the same number of steps with one launch per frame (a single 1920x1080x1024spp render is
         # this figure); not the headline value
-        f_elapsed = measure(W, H, spp, limit, 0, args.steps, False)[0]
+        f_elapsed = measure(W, H, spp, limit, 0, args.steps, False)["elapsed"]
         per_frame = {"value": W * H * spp * args.steps / f_elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": f_elapsed / args.steps * 1e3,
-                     "note": "one launch per step"}
+                     "frames_per_s": args.steps / f_elapsed, "note": "one launch per step (the reference's main-loop cadence, src/main.cu:415-431)"}
     extras = {}
     if world > 1 and not args.no_extras:
         if args.scaling != "weak":
             # side figure: weak scaling (image area grows with N at the same aspect ratio and field of view)
             w_W, w_H = weak_image(args.width, args.height, world)
-            w_el = measure(w_W, w_H, spp, limit, 1, args.steps, batched)[0]
+            w_el = measure(w_W, w_H, spp, limit, 1, args.steps, batched)["elapsed"]
             extras["weak_scaling"] = {"image": "%dx%d" % (w_W, w_H), "spp": spp, "steps": args.steps, "value": w_W * w_H * spp * args.steps / w_el / 1e6,
                                       "unit": "Msamples/s", "ms_per_step": w_el / args.steps * 1e3}
-        if args.config != 4:
+        if args.config != 4 and args.scene == "monkey":
             # side figure: BASELINE configs[4] (3840x2160, 4096 spp), two progressive frames in one launch per rank
             _, c_W, c_H, c_spp, c_limit = CONFIGS[4]
-            if args.scene == "monkey":
-                c_el = measure(c_W, c_H, c_spp if args.spp == CONFIGS[args.config][3] else args.spp, c_limit, 0, 2, True)[0]
-                c_spp_used = c_spp if args.spp == CONFIGS[args.config][3] else args.spp
-                extras["config4"] = {"workload": "monkey scene, %dx%d, %d spp, %d bounces (BASELINE configs[4])" % (c_W, c_H, c_spp_used, c_limit),
-                                     "steps": 2, "warmup": 0, "value": c_W * c_H * c_spp_used * 2 / c_el / 1e6, "unit": "Msamples/s", "ms_per_step": c_el / 2 * 1e3}
+            c_spp_used = c_spp if args.spp == CONFIGS[3][3] else args.spp
+            c_el = measure(c_W, c_H, c_spp_used, c_limit, 0, 2, True)["elapsed"]
+            extras["config4"] = {"workload": "monkey scene, %dx%d, %d spp, %d bounces (BASELINE configs[4])" % (c_W, c_H, c_spp_used, c_limit),
+                                 "steps": 2, "warmup": 1, "value": c_W * c_H * c_spp_used * 2 / c_el / 1e6, "unit": "Msamples/s", "ms_per_step": c_el / 2 * 1e3}
+    # the C ABI's one-thread multi-GPU path, from rank 0 while the other ranks wait (their GPUs are idle)
+    capi_devices = None
+    if args.capi_multi:
+        capi_devices = [int(x) for x in args.capi_multi.split(",")]
+    elif world > 1 and not args.no_extras and batched:
+        capi_devices = [0] * world if args.share_gpu else list(range(min(world, torch.cuda.device_count())))
+    if capi_devices:
+        if rank == 0:
+            try:
+                extras["capi_multi"] = capi_multi(rt, torch, so, sky, capi_devices, W, H, spp, limit, args.warmup, args.steps, frame if batched else None)
+            except Exception as e:                      # noqa: BLE001  (a side measurement must not lose the headline)
+                extras["capi_multi"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if world > 1:
+            dist.barrier(group=host_group)
 
     samples_per_step = W * H * spp
     value = samples_per_step * args.steps / elapsed / 1e6
 
     # per-launch figures for THIS rank's kernel
-    my_pixels = 0
-    for b in dm.owned_bands(H, band_rows, rank, world):
-        my_pixels += (min((b + 1) * band_rows, H) - b * band_rows) * W
+    my_pixels = m["my_pixels"]
     avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
     avg_frames = sum(frames_per_launch) / float(len(frames_per_launch))
     flat = so.debug_flatten()
@@ -325,25 +424,31 @@ def main():
                         + ("; a multi-frame launch writes one plane of per-pixel means per frame, folded into the frame by a small kernel behind it" if batched else "")}
 
     cfg_idx = [i for i, c in CONFIGS.items() if c == (args.scene, W, H, spp, limit)]
+    cfg_note = ""
+    if cfg_idx:
+        cfg_note = " (the reference's default workload, src/main.cu:318-330)" if cfg_idx[0] == "ref0" else " (BASELINE configs[%d])" % cfg_idx[0]
     ranks_info = None
     if world > 1:
         mine = {"rank": rank, "device": torch.cuda.get_device_name(local_rank), "local_rank": local_rank,
                 "kernel_ms": [round(x, 3) for x in kernel_ms]}
         allr = [None] * world
         dist.all_gather_object(allr, mine)
-        ranks_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": allr}
+        ranks_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": allr, "partition": m["partition"]}
         if backend_note:
             ranks_info["note"] = backend_note
     out = {"metric": "Msamples/sec (WxHxspp) at %dx%d, %d bounces" % (W, H, limit), "value": value, "unit": "Msamples/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-           "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "%s scene, %dx%d, %d spp, %d bounces, antialias on, time_ms 12345%s"
-                      % (args.scene, W, H, spp, limit, (" (BASELINE configs[%d])" % cfg_idx[0]) if cfg_idx else ""),
-                      "parallelism": "image bands of 8 rows interleaved over %d GPU(s) + gather to rank 0" % world,
+           # every N renders the SAME image (strong scaling) unless --scaling weak; an N = 1 line is the curve's first point
+           "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "backend": backend, "world_size": world,
+           "config": {"workload": "%s scene, %dx%d, %d spp, %d bounces, antialias on, time_ms 12345%s" % (args.scene, W, H, spp, limit, cfg_note),
+                      "parallelism": ("%s over %d GPUs + gather to rank 0" % (m["partition"]["kind"], world)) if world > 1 else "one GPU, whole image",
                       "steps": ("consecutive progressive frames (seeds 12345 + i) in launches of up to %d frames per rank, gathered once" % MAX_BATCH) if batched
                                else "one launch + one gather per step",
                       "image": "%dx%d" % (W, H),
-                      "threads_per_block": info["threads_per_block"], "blocks_per_cu": info["blocks_per_cu"], "lds_bytes": info["lds_bytes"]},
+                      "threads_per_block": info["threads_per_block"], "blocks_per_cu": info["blocks_per_cu"], "lds_bytes": info["lds_bytes"],
+                      "scene_in_lds": info["scene_in_lds"], "triangles": info["num_triangles"]},
+           "frames_per_s": args.steps / elapsed,
            "roofline": roofline}
     if ranks_info is not None:
         out["ranks"] = ranks_info
@@ -362,6 +467,7 @@ def main():
                            "algorithmic_flops_per_sample": fps,
                            "per_sample": {k: v / float(st["samples"]) for k, v in st.items() if k != "samples"}}
             out["gpu_over_cpu"] = value / cb["value"]
+            out["gpu_over_cpu_all_threads"] = value / cb["all_threads"]["value"]
         if frame is not None:
             out["frame_mean"] = float(frame.mean().item())
             if args.check:
@@ -379,6 +485,43 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def capi_multi(rt, torch, scene_objects, sky, devices, W, H, spp, limit, warmup, steps, reference_frame):
+    """`steps` progressive frames through rt_render_multi_device (include/rt_amd.h; replaces run_ray_tracer
+    src/dispatch.cu:127-163 for a node) from THIS process over `devices`: one host thread, one context per entry,
+    cost-balanced tile lists, peer copies to devices[0].  Two untimed calls first (the view's first call measures
+    the tiles on an interleaved ownership, the second deals them out by cost), then the timed call renders frames
+    0..steps-1 into a fresh frame, which must equal `reference_frame` (the torch.distributed run's) bit for bit."""
+    ctxs = [rt.Context(d) for d in devices]
+    scenes = [c.commit(scene_objects) for c in ctxs]
+    cam, rd = rt.Camera(W, H), rt.RenderData(spp, limit, True, sky)
+    root = torch.device("cuda", devices[0])
+    with torch.cuda.device(root):
+        s0 = torch.cuda.current_stream(root).cuda_stream
+        scratch = torch.zeros((H, W, 3), dtype=torch.float32, device=root)
+        frame = torch.zeros((H, W, 3), dtype=torch.float32, device=root)
+        rt.render_multi_device(ctxs, scenes, cam, rd, [12345 + i for i in range(max(1, warmup))], 0, scratch.data_ptr(), stream=s0)
+        rt.render_multi_device(ctxs, scenes, cam, rd, [12345], 0, scratch.data_ptr(), stream=s0)
+
+        def sync():
+            torch.cuda.synchronize(root)
+            for c in ctxs:
+                c.synchronize()
+        sync()
+        t0 = time.perf_counter()
+        rt.render_multi_device(ctxs, scenes, cam, rd, [12345 + i for i in range(steps)], 0, frame.data_ptr(), stream=s0)
+        sync()
+        elapsed = time.perf_counter() - t0
+        out = {"entry": "rt_render_multi_device (one host thread, cost-balanced tile lists, peer copies to the first device)",
+               "devices": devices, "steps": steps, "value": W * H * spp * steps / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": elapsed / steps * 1e3,
+               "kernel_ms_per_rank": [round(c.last_kernel_ms(), 3) for c in ctxs],
+               "p2p": [{"pair": [devices[0], d], "direct": bool(ctxs[0].peer_access(c) == 1)} for d, c in list(zip(devices, ctxs))[1:]]}
+        if reference_frame is not None:
+            ref = reference_frame.to(root).contiguous()
+            out["equals_gathered_frame"] = bool(torch.equal(frame.view(torch.int32), ref.view(torch.int32)))
+    del scenes, ctxs
+    return out
 
 
 def weak_image(width, height, world):

@@ -175,17 +175,29 @@ rt_status rt_render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_camera *
                            const int32_t *times_ms, int32_t n_frames, int32_t *frame_num, float *previous_render);
 
 /* Device-buffer form for callers that own HBM (PyTorch tensors) and streams.
- * Rows are handed out in bands of `band_rows` rows; this call renders the bands whose index b
- * satisfies b % band_stride == band_first (band_stride = number of GPUs, band_first = rank).
- * d_prev (nullable = zeros) is always a full W*H*3 frame.  If compact == 0, d_out is a full
- * frame and only the owned rows are written; if compact != 0, d_out holds the owned bands
- * back to back (band k of this rank at row k*band_rows), which is the shape an all-gather wants.
+ * Which pixels a call renders is given in one of two forms ("tile rows or tile list"):
+ *  - bands: rows are handed out in bands of `band_rows` rows; the call renders the bands whose index b
+ *    satisfies b % band_stride == band_first (band_stride = number of GPUs, band_first = rank);
+ *  - a tile list (tile_list != NULL; the band fields are then ignored): the call renders the 8x8 tiles
+ *    tile_list[0..num_tiles), each named by its index ty * ceil(width / 8) + tx in the image and listed at
+ *    most once.  This is the form cost-balanced ownership over GPUs uses (rt_partition_tiles below).
+ * d_prev (nullable = zeros) is always a full W*H*3 frame.  If compact == 0, d_out is a full frame and only
+ * the owned pixels are written; if compact != 0, d_out holds only what the call owns: the owned bands back
+ * to back (band k of this rank at row k*band_rows: the shape an all-gather wants), or the listed tiles back
+ * to back (tile k at floats [192 k, 192 k + 192): its 64 pixels row by row; slots of a ragged edge tile that
+ * lie outside the image are never written).
+ * tile_cost (nullable, with a tile list only): one cost estimate per listed tile, as rt_tile_costs reported
+ * them for an earlier launch of the same view; the launch is then scheduled longest job first at once
+ * instead of measuring the costs itself first.  The arrays are host memory, read during the call.
  * The launch is asynchronous on `hip_stream` (a hipStream_t, NULL = default stream). */
 typedef struct rt_tile_spec {
     int32_t band_rows;       /* > 0, multiple of 8 */
     int32_t band_first;
     int32_t band_stride;
     int32_t compact;
+    const uint32_t *tile_list;
+    const uint32_t *tile_cost;
+    int32_t num_tiles;
 } rt_tile_spec;
 
 rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
@@ -205,8 +217,38 @@ rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *
 rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
                                  const int32_t *times_ms, int32_t n_frames, int32_t frame_num, const rt_tile_spec *tiles,
                                  float *d_frame, void *hip_stream);
-/* number of rows a rank owns under a tile spec (host helper for sizing compact buffers) */
+/* number of rows a rank owns under a band tile spec (host helper for sizing compact buffers) */
 int32_t rt_tile_owned_rows(const rt_tile_spec *tiles, int32_t height);
+
+/* What the tiles of this context's current view cost: the first launch of a view (scene, camera, image size,
+ * tile spec) adds up, per tile, the work of its pixels (traversal steps, generated rays and shaded hits,
+ * weighted); this call waits for that launch and copies the figures out: tile_ids[i] = the tile's index in
+ * the image (ty * ceil(width / 8) + tx), costs[i] its cost, for i < *count (= the tiles of that launch, at
+ * most `capacity`).  RT_ERR_INVALID if no launch of the current view has collected costs.  The reference
+ * has no counterpart (one GPU, one thread per pixel, src/dispatch.cu:136-139); this is what lets N GPUs
+ * share a frame by cost instead of by area. */
+rt_status rt_tile_costs(rt_ctx *ctx, uint32_t *tile_ids, uint32_t *costs, int32_t capacity, int32_t *count);
+
+/* Ownership of the tiles_x x tiles_y tiles of an image over n_ranks GPUs: owner[ty * tiles_x + tx] = rank.
+ * cost == NULL: interleaved, owner = (tx + ty) % n_ranks (what a view's first, cost-collecting launch uses).
+ * Otherwise cost[tile] is its measured cost (rt_tile_costs, summed over the ranks that rendered the view)
+ * and tiles are dealt longest-processing-time-first: by decreasing cost, each to the rank with the least
+ * cost so far (ties: the lower tile index first, the lower rank).  Deterministic: every rank that calls it
+ * with the same costs gets the same owners.  Any partition renders the same image (a pixel depends only on
+ * its index, seed and previous value, src/raytracer.cu:118-131). */
+rt_status rt_partition_tiles(const uint32_t *cost, int32_t tiles_x, int32_t tiles_y, int32_t n_ranks, int32_t *owner);
+
+/* The exchange step for tile lists on one GPU: copies between a compact image (the listed tiles back to
+ * back, as a compact tile-list render writes them) and a full W*H*3 frame, both on ctx's GPU, asynchronously
+ * on hip_stream.  to_frame != 0: frame <- compact (what the root does with every rank's gathered tiles);
+ * to_frame == 0: compact <- frame (handing the image so far to its owners).  tile_list is host memory. */
+rt_status rt_tiles_copy_device(rt_ctx *ctx, float *d_compact, float *d_frame, int32_t width, int32_t height,
+                               const uint32_t *tile_list, int32_t num_tiles, int32_t to_frame, void *hip_stream);
+
+/* How many progressive frames the multi-frame entry points put into one launch for an image of this size on
+ * this context's GPU: at most 32, fewer when that many per-frame planes (12 bytes per pixel each) would take
+ * more than a quarter of the GPU's memory. */
+int32_t rt_max_batch_frames(rt_ctx *ctx, int32_t width, int32_t height);
 
 /* Kernel timing by HIP events recorded on the launch stream around the render kernel of the
  * most recent rt_render / rt_render_device call; blocks until that kernel has finished. */
@@ -222,7 +264,10 @@ rt_status rt_ctx_synchronize(rt_ctx *ctx);
  * only on its own coordinates, seed and previous value, so any partition gives the single-GPU image bit
  * for bit) on its own context, asynchronously; the band buffers travel to ranks[0]'s GPU with one peer
  * copy per rank (xGMI) and are de-interleaved there.  There is no reduction, hence no collective.
- * Every rank needs the scene committed on ITS context; a context may appear once. */
+ * Every rank needs the scene committed on ITS context; a context may appear once.
+ * rt_render_multi[_device] own the partition: the first call for a view deals the tiles out interleaved and
+ * measures what they cost; from the second call on every rank owns a cost-balanced tile list
+ * (rt_partition_tiles), so the ranks finish together. */
 typedef struct rt_rank {
     rt_ctx *ctx;
     const rt_scene *scene;
@@ -234,18 +279,24 @@ typedef struct rt_rank {
 rt_status rt_render_multi(const rt_rank *ranks, int32_t n_ranks, const rt_camera *cam, const rt_render_settings *rs,
                           const int32_t *times_ms, int32_t n_frames, int32_t *frame_num, float *previous_render);
 /* Device-buffer form: d_frame is a full W*H*3 frame on ranks[0]'s GPU, updated in place (its content is
- * the image after frame_num - 1 when frame_num > 0, ignored otherwise); bands of band_rows rows (a
- * positive multiple of 8).  Asynchronous: the frame is complete in the order of hip_stream (a stream of
+ * the image after frame_num - 1 when frame_num > 0, ignored otherwise).  band_rows > 0 (a multiple of 8):
+ * the static partition of round 2 - rank i owns the bands b % n_ranks == i; band_rows == 0: cost-balanced
+ * tile lists as described above.  Asynchronous: the frame is complete in the order of hip_stream (a stream of
  * ranks[0]'s GPU, NULL = default stream); rt_ctx_synchronize on each rank reports kernel errors. */
 rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_ranks, const rt_camera *cam, const rt_render_settings *rs,
                                  const int32_t *times_ms, int32_t n_frames, int32_t frame_num, int32_t band_rows,
                                  float *d_frame, void *hip_stream);
 /* The exchange step alone, for callers that launch the ranks themselves (rt_render_device[_batch] with a
- * compact tile spec): the band buffer d_bands of the rank `src_tiles` describes, on src's GPU, lands in the
- * full frame d_frame on root's GPU - one peer copy + a de-interleave on root_stream - ordered behind src's
- * most recent launch. */
+ * compact tile spec, bands or list): the compact buffer d_bands of the rank `src_tiles` describes, on src's GPU,
+ * lands in the full frame d_frame on root's GPU - one peer copy + a de-interleave on root_stream - ordered
+ * behind src's most recent launch. */
 rt_status rt_gather(rt_ctx *root, float *d_frame, int32_t width, int32_t height, rt_ctx *src, const float *d_bands,
                     const rt_tile_spec *src_tiles, void *root_stream);
+
+/* Direct (xGMI) access from a's GPU to b's memory and back: enables it if need be and reports 1 (peer access is
+ * on in both directions: copies between the two go GPU to GPU), 0 (refused or unavailable: the runtime stages
+ * them through the host - still correct, slower) or 1 when both contexts share a GPU; < 0: -rt_status. */
+int32_t rt_peer_access(rt_ctx *a, rt_ctx *b);
 
 /* float -> RGBA8 display conversion of src/main.cu:343-371 (int(px*255), clamp, alpha 255),
  * on the device: d_rgb W*H*3 floats -> d_rgba W*H*4 bytes */

@@ -45,7 +45,8 @@ class rt_render_settings(C.Structure):
 
 
 class rt_tile_spec(C.Structure):
-    _fields_ = [("band_rows", C.c_int32), ("band_first", C.c_int32), ("band_stride", C.c_int32), ("compact", C.c_int32)]
+    _fields_ = [("band_rows", C.c_int32), ("band_first", C.c_int32), ("band_stride", C.c_int32), ("compact", C.c_int32),
+                ("tile_list", C.POINTER(C.c_uint32)), ("tile_cost", C.POINTER(C.c_uint32)), ("num_tiles", C.c_int32)]
 
 
 class rt_rank(C.Structure):
@@ -76,6 +77,7 @@ ABI_SYMBOLS = [
     "rt_obj_num_triangles", "rt_obj_get_triangles", "rt_camera_default", "rt_camera_make",
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_scene_commit", "rt_scene_destroy",
     "rt_scene_get_info", "rt_render", "rt_render_frames", "rt_render_device", "rt_render_device_batch", "rt_tile_owned_rows", "rt_last_kernel_ms",
+    "rt_tile_costs", "rt_partition_tiles", "rt_tiles_copy_device", "rt_max_batch_frames", "rt_peer_access",
     "rt_ctx_synchronize", "rt_render_multi", "rt_render_multi_device", "rt_gather",
     "rt_to_rgba8_device", "rt_debug_flatten", "rt_debug_read_stats", "rt_debug_eval", "rt_version",
 ]
@@ -166,6 +168,12 @@ def lib():
     L.rt_render_device_batch.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
                                          C.POINTER(rt_tile_spec), vp, vp]
     L.rt_tile_owned_rows.argtypes = [C.POINTER(rt_tile_spec), C.c_int32]
+    u32p = C.POINTER(C.c_uint32)
+    L.rt_tile_costs.argtypes = [vp, u32p, u32p, C.c_int32, C.POINTER(C.c_int32)]
+    L.rt_partition_tiles.argtypes = [u32p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+    L.rt_tiles_copy_device.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, u32p, C.c_int32, C.c_int32, vp]
+    L.rt_max_batch_frames.argtypes = [vp, C.c_int32, C.c_int32]
+    L.rt_peer_access.argtypes = [vp, vp]
     L.rt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.rt_ctx_synchronize.argtypes = [vp]
     L.rt_render_multi.argtypes = [C.POINTER(rt_rank), C.c_int32, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.POINTER(C.c_int32), C.c_int32,
@@ -536,8 +544,26 @@ class Context:
         return ms.value
 
     def synchronize(self):
-        """waits for this context's most recent launch; raises if the kernel reported an incomplete frame"""
+        """waits for this context's most recent launch"""
         self._check(lib().rt_ctx_synchronize(self._h))
+
+    def tile_costs(self):
+        """(tile indices in the image, costs) of the current view's tiles as its first launch measured them
+        (rt_tile_costs; waits for that launch)"""
+        n = C.c_int32()
+        self._check(lib().rt_tile_costs(self._h, None, None, 0, C.byref(n)))
+        ids, costs = np.empty(n.value, np.uint32), np.empty(n.value, np.uint32)
+        u32p = C.POINTER(C.c_uint32)
+        self._check(lib().rt_tile_costs(self._h, ids.ctypes.data_as(u32p), costs.ctypes.data_as(u32p), n.value, C.byref(n)))
+        return ids, costs
+
+    def max_batch_frames(self, width, height):
+        """frames the multi-frame entry points put into one launch for this image size (rt_max_batch_frames)"""
+        return lib().rt_max_batch_frames(self._h, int(width), int(height))
+
+    def peer_access(self, other):
+        """1: copies between the two contexts' GPUs go direct (xGMI), 0: staged by the runtime (rt_peer_access)"""
+        return lib().rt_peer_access(self._h, other._h)
 
     def __del__(self):
         try:
@@ -598,22 +624,69 @@ def render_frames(ctx, scene, camera, render_data, data, times_ms):
     return buf
 
 
-def render_device(ctx, scene, camera, render_data, time_ms, frame_num, d_out, d_prev=None,
-                  band_rows=8, band_first=0, band_stride=1, compact=False, stream=None):
-    """Device-buffer form: d_out / d_prev are device pointers (ints, e.g. torch.Tensor.data_ptr())."""
+def _tile_spec(band_rows, band_first, band_stride, compact, tile_list, tile_cost):
+    """rt_tile_spec + the arrays it points at (keep the second value alive for the duration of the call)"""
     ts = rt_tile_spec(int(band_rows), int(band_first), int(band_stride), int(bool(compact)))
+    keep = None
+    if tile_list is not None:
+        ids = np.ascontiguousarray(tile_list, dtype=np.uint32)
+        # (a NULL list pointer means "bands": an empty list still needs an address)
+        backing = ids if ids.size else np.zeros(1, np.uint32)
+        ts.tile_list = backing.ctypes.data_as(C.POINTER(C.c_uint32))
+        ts.num_tiles = int(ids.size)
+        cost = None
+        if tile_cost is not None:
+            cost = np.ascontiguousarray(tile_cost, dtype=np.uint32)
+            assert cost.size == ids.size
+            if cost.size:
+                ts.tile_cost = cost.ctypes.data_as(C.POINTER(C.c_uint32))
+        keep = (ids, backing, cost)
+    return ts, keep
+
+
+def render_device(ctx, scene, camera, render_data, time_ms, frame_num, d_out, d_prev=None,
+                  band_rows=8, band_first=0, band_stride=1, compact=False, stream=None, tile_list=None, tile_cost=None):
+    """Device-buffer form: d_out / d_prev are device pointers (ints, e.g. torch.Tensor.data_ptr()).  tile_list: the
+    8x8 tiles to render (indices ty * ceil(W / 8) + tx) instead of bands."""
+    ts, keep = _tile_spec(band_rows, band_first, band_stride, compact, tile_list, tile_cost)
     ctx._check(lib().rt_render_device(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), int(time_ms), int(frame_num),
                                       C.byref(ts), C.c_void_p(d_prev or 0), C.c_void_p(d_out), C.c_void_p(stream or 0)))
+    del keep
 
 
 def render_device_batch(ctx, scene, camera, render_data, times_ms, frame_num, d_frame,
-                        band_rows=8, band_first=0, band_stride=1, compact=False, stream=None):
+                        band_rows=8, band_first=0, band_stride=1, compact=False, stream=None, tile_list=None, tile_cost=None):
     """len(times_ms) consecutive progressive frames in ONE launch, accumulated in place in the device
     buffer d_frame (bit-identical to that many render_device calls; see rt_render_device_batch)."""
-    ts = rt_tile_spec(int(band_rows), int(band_first), int(band_stride), int(bool(compact)))
+    ts, keep = _tile_spec(band_rows, band_first, band_stride, compact, tile_list, tile_cost)
     t = (C.c_int32 * len(times_ms))(*[int(x) for x in times_ms])
     ctx._check(lib().rt_render_device_batch(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), t, len(times_ms), int(frame_num),
                                             C.byref(ts), C.c_void_p(d_frame), C.c_void_p(stream or 0)))
+    del keep
+
+
+def partition_tiles(width, height, n_ranks, cost=None):
+    """owner[ty * tiles_x + tx] = rank (rt_partition_tiles): interleaved without costs, longest-processing-time-first
+    with them.  Returns an int32 array over the image's 8x8 tiles."""
+    tiles_x, tiles_y = (int(width) + 7) // 8, (int(height) + 7) // 8
+    owner = np.empty(tiles_x * tiles_y, np.int32)
+    cp = None
+    if cost is not None:
+        cost = np.ascontiguousarray(cost, dtype=np.uint32)
+        assert cost.size == owner.size
+        cp = cost.ctypes.data_as(C.POINTER(C.c_uint32))
+    st = lib().rt_partition_tiles(cp, tiles_x, tiles_y, int(n_ranks), owner.ctypes.data_as(C.POINTER(C.c_int32)))
+    if st != RT_OK:
+        raise ValueError("rt_partition_tiles: bad argument")
+    return owner
+
+
+def tiles_copy_device(ctx, d_compact, d_frame, width, height, tile_list, to_frame=True, stream=None):
+    """compact tile-list image <-> full frame on ctx's GPU (rt_tiles_copy_device)"""
+    ids = np.ascontiguousarray(tile_list, dtype=np.uint32)
+    backing = ids if ids.size else np.zeros(1, np.uint32)
+    ctx._check(lib().rt_tiles_copy_device(ctx._h, C.c_void_p(d_compact), C.c_void_p(d_frame), int(width), int(height),
+                                          backing.ctypes.data_as(C.POINTER(C.c_uint32)), int(ids.size), int(bool(to_frame)), C.c_void_p(stream or 0)))
 
 
 def _ranks(ctxs, scenes):
@@ -636,17 +709,19 @@ def render_multi(ctxs, scenes, camera, render_data, data, times_ms):
     return buf
 
 
-def render_multi_device(ctxs, scenes, camera, render_data, times_ms, frame_num, d_frame, band_rows=8, stream=None):
-    """device-buffer form (rt_render_multi_device): d_frame is a full frame on ctxs[0]'s GPU, updated in place"""
+def render_multi_device(ctxs, scenes, camera, render_data, times_ms, frame_num, d_frame, band_rows=0, stream=None):
+    """device-buffer form (rt_render_multi_device): d_frame is a full frame on ctxs[0]'s GPU, updated in place.
+    band_rows = 0: cost-balanced tile lists (the first call of a view measures the tiles); > 0: static bands"""
     t = (C.c_int32 * len(times_ms))(*[int(x) for x in times_ms])
     ctxs[0]._check(lib().rt_render_multi_device(_ranks(ctxs, scenes), len(ctxs), C.byref(camera.c), C.byref(render_data.c), t, len(times_ms),
                                                 int(frame_num), int(band_rows), C.c_void_p(d_frame), C.c_void_p(stream or 0)))
 
 
-def gather(root, d_frame, width, height, src, d_bands, band_rows, band_first, band_stride, stream=None):
-    """the exchange step alone (rt_gather): src's compact band buffer -> the full frame on root's GPU"""
-    ts = rt_tile_spec(int(band_rows), int(band_first), int(band_stride), 1)
+def gather(root, d_frame, width, height, src, d_bands, band_rows=8, band_first=0, band_stride=1, stream=None, tile_list=None):
+    """the exchange step alone (rt_gather): src's compact buffer (bands, or the tiles of tile_list) -> the full frame on root's GPU"""
+    ts, keep = _tile_spec(band_rows, band_first, band_stride, True, tile_list, None)
     root._check(lib().rt_gather(root._h, C.c_void_p(d_frame), int(width), int(height), src._h, C.c_void_p(d_bands), C.byref(ts), C.c_void_p(stream or 0)))
+    del keep
 
 
 def debug_eval(ctx, op, bits):

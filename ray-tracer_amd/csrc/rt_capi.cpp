@@ -1,6 +1,6 @@
 /*
  * rt_capi.cpp — the device half of the C ABI (include/rt_amd.h): context, scene upload,
- * render launches, timing.  Replaces the reference's host<->device seam
+ * render launches, tile ownership over GPUs, timing.  Replaces the reference's host<->device seam
  * (src/dispatch.cu:104-163): where the reference allocates and frees four device buffers per
  * frame and copies the frame element-wise out of managed memory, the context here keeps
  * persistent HBM frame buffers and the device-buffer entry point takes caller-owned HBM.
@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -22,17 +24,46 @@
 
 extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream);
 extern "C" int rt_kernel_blocks_per_cu(int has_mesh, int scene_in_lds, int threads, size_t lds_bytes);
-extern "C" hipError_t rt_launch_render_pool(const rt_kernel_args *args, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t rt_launch_blend(const float *partial, long long plane_floats, int num_frames, int frame_num, float *frame, long long n_floats, hipStream_t stream);
+extern "C" hipError_t rt_launch_blend_tiles(const float *partial, long long plane_floats, int num_frames, int frame_num, float *frame,
+                                            const uint32_t *tile_list, int n_tiles, int tiles_x, int W, int H, hipStream_t stream);
+extern "C" hipError_t rt_launch_tiles_copy(float *compact, float *frame, const uint32_t *tile_list, int n_tiles, int tiles_x, int W, int H, int to_frame, hipStream_t stream);
 extern "C" hipError_t rt_launch_eval(int op, const uint32_t *in, uint32_t *out, int n, hipStream_t stream);
 extern "C" hipError_t rt_launch_rgba8(const float *rgb, int n_pixels, uint8_t *out, hipStream_t stream);
 
 #define RT_LDS_LIMIT 163840   /* 160 KiB per CU / per workgroup on gfx950 */
 #define RT_MAX_BLOCKS_PER_CU 6
 
+namespace {
+
+/* a tile list on the device, found again by content (lists are a few KB to ~130 KB and change only with the view) */
+struct DevList {
+    uint64_t hash = 0;
+    int n = 0;
+    uint32_t *d = nullptr;
+};
+
+/* the root's landing area for one source context's compact image (rt_gather, rt_render_multi_device) */
+struct Stage {
+    float *d = nullptr;
+    size_t cap = 0;                      /* floats */
+    hipEvent_t ev_free = nullptr;        /* recorded on the root's stream after the last de-interleave that read the area */
+    bool used = false;
+};
+
+/* rt_render_multi[_device] with cost-balanced tile lists: what the root remembers between calls */
+struct MultiState {
+    std::vector<uint32_t> key;           /* camera, image size, number of ranks, scene ids */
+    int stage = 0;                       /* 0 nothing; 1 the interleaved lists are in use and a call has collected costs; 2 balanced */
+    std::vector<std::vector<uint32_t>> lists, costs;      /* per rank: its tiles (image indices) and their measured costs */
+};
+
+}  // namespace
+
 struct rt_ctx {
     int device = 0;
     int num_cus = 0;
+    size_t total_mem = 0;
     std::string err;
     uint32_t *tile_counter = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -42,38 +73,43 @@ struct rt_ctx {
      * previous one first waits for that one's stop event (one launch in flight per context). */
     hipStream_t last_stream = nullptr;
     bool launched = false;
-    /* multi-GPU entry points (rt_render_multi*): this rank's compact band buffer, its stream and "bands
-     * are in the root's staging area" event; on the root also the staging area for every rank's bands */
+    /* multi-GPU entry points (rt_render_multi*): this rank's compact buffer, its stream and "my image is in the root's
+     * staging area" event; on the root also the staging areas, one per source context */
     float *d_bands = nullptr;
     size_t bands_cap = 0;                /* floats */
-    float *d_stage = nullptr;
-    size_t stage_cap = 0;                /* floats */
+    std::map<rt_ctx *, Stage> stages;
     hipStream_t multi_stream = nullptr;
     hipEvent_t ev_multi = nullptr;
+    MultiState multi;
+    std::map<int, int> peer_ok;          /* device -> 1 direct access both ways, 0 refused */
     /* persistent frame buffers for the host-buffer entry point */
     float *d_prev = nullptr, *d_out = nullptr;
     size_t frame_bytes = 0;
-    /* cached tile order (longest-job-first heuristic) for the last (scene, camera, tile spec) */
+    /* ---- the current view: (scene, camera, image, tile spec).  Its tiles, their order and what they cost ---- */
+    std::vector<uint32_t> order_key;     /* what the view state below was built for */
+    std::vector<uint32_t> tiles_host;    /* local tile t of the launch -> the tile's index in the image */
+    std::vector<uint32_t> order_host;    /* ticket -> local tile (host copy of d_tile_order), when the view uses an order */
+    bool use_order = false;
     uint32_t *d_tile_order = nullptr;
+    size_t tile_order_cap = 0;
+    uint32_t *d_tile_cost = nullptr;     /* per tile: the weighted work of its pixels, collected by the first launch of a view */
+    size_t tile_cost_cap = 0;
+    int cost_state = 0;                  /* 0 nothing, 1 a launch of this view collected costs, 2 cost_host holds them (and the order is refined) */
+    std::vector<uint32_t> cost_host;     /* the measured (or caller-supplied) costs, per local tile */
+    int order_num_heavy = 0;             /* refined order: how many leading tiles go first for ALL frames of a multi-frame launch */
     float *d_partial = nullptr;          /* multi-frame launches: one plane of per-pixel frame means per frame */
     size_t partial_cap = 0;              /* floats */
-    size_t tile_order_cap = 0;
-    std::vector<uint32_t> order_key;     /* what the cached order was built for */
-    std::vector<uint32_t> order_host;    /* that order (host copy) */
-    uint32_t *d_tile_cost = nullptr;     /* per tile: traversal macro steps of its pixels, collected by the first launch of a view */
-    int cost_state = 0;                  /* 0 nothing, 1 the last launch with this key collected costs, 2 the order has been refined with them */
-    int order_num_heavy = 0;             /* refined order: how many leading tiles go first for ALL frames of a multi-frame launch */
-    int heavy_top = 1024;                /* RT_AMD_HEAVY_TOP: that many at most (0 = never refine) */
     /* multi-frame launches, once the tile costs of the view are known: the whole schedule (ticket -> tile, frame),
      * longest job first over all frames (see build_job_order) */
-    std::vector<uint32_t> cost_host;     /* the measured costs (per tile of the launch) */
     uint32_t *d_job_order = nullptr;
     size_t job_cap = 0;
     int job_frames = 0;                  /* what the uploaded schedule was built for (with order_key) */
+    std::vector<DevList> dev_lists;
+    /* knobs (RT_AMD_*), none changes an image */
+    int heavy_top = 1024;                /* RT_AMD_HEAVY_TOP: the refined order moves that many tiles at most to the front (0 = never refine) */
     int lpt = 1;                         /* RT_AMD_LPT=0: the round-1 ticket order (heavy tiles of frame 0, 1, ... first) */
     int lpt_top = 1 << 30;               /* RT_AMD_LPT_TOP: at most this many tiles (most expensive first) are scheduled by cost */
     int heavy_first = 1;                 /* RT_AMD_HEAVY_FIRST=0 disables */
-    /* scheduling thresholds (defaults in rt_device_scene.h) */
     int work_threshold = RT_DEF_WORK_THRESHOLD;      /* lanes; RT_AMD_WORK_THRESHOLD */
     int descend_keep = RT_DEF_DESCEND_KEEP;       /* RT_AMD_DESCEND_KEEP (0..64): 0 = run every descent to its end */
     int tile_scatter = 1;        /* RT_AMD_TILE_SCATTER=0: hand tiles out in raster order */
@@ -81,8 +117,6 @@ struct rt_ctx {
     int hit_break = RT_DEF_HIT_BREAK;          /* lanes; RT_AMD_HIT_BREAK */
     int hit_low = RT_DEF_HIT_LOW, mix_break = RT_DEF_MIX_BREAK;   /* RT_AMD_HIT_LOW, RT_AMD_MIX_BREAK (0 = that rule off) */
     int shade_batch = RT_DEF_SHADE_BATCH;        /* lanes; RT_AMD_SHADE_BATCH (1..64) */
-    int use_pool = 0;            /* RT_AMD_POOL=1: mesh scenes through the workgroup ray pool (rt_render_pool_kernel); an experiment, slower */
-    int pool_fill = 16, pool_low = 16, pool_leaf_batch = 48;    /* RT_AMD_POOL_FILL / _LOW / _LEAF_BATCH */
 };
 
 struct rt_scene {
@@ -97,7 +131,6 @@ struct rt_scene {
     int scene_in_lds = 1;    /* 0: scene read from global memory (does not fit LDS) */
     uint32_t uid = 0;        /* distinguishes scenes in the tile-order cache (addresses get reused) */
     size_t lds_bytes = 0;
-    int pool = 0;            /* 1: rendered by the pooled kernel (threads / lds_bytes are its) */
 };
 
 namespace {
@@ -121,20 +154,69 @@ rt_status set_err(rt_ctx *ctx, rt_status code, const std::string &msg)
     return code;
 }
 
-/* the pooled kernel raises tile_counter[1] when one of its queue waits gave up (a bug, never a
- * property of the input): the frame is then not to be trusted */
-rt_status check_kernel_flag(rt_ctx *ctx)
+uint64_t fnv1a(const void *data, size_t bytes, uint64_t h = 1469598103934665603ull)
 {
-    uint32_t flag = 0;
-    hipError_t e = hipMemcpy(&flag, ctx->tile_counter + 1, 4, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) return hip_fail(ctx, e, "reading kernel status");
-    if (flag) return set_err(ctx, RT_ERR_HIP, "Error from HIP (render kernel): traversal queue watchdog fired, frame incomplete");
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < bytes; i++) { h ^= p[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+/* `list` (host) on ctx's GPU.  A new list is uploaded on `stream` and the call waits for the upload (the source is the
+ * caller's memory); a list seen before costs a hash. */
+rt_status device_tile_list(rt_ctx *ctx, const uint32_t *list, int n, hipStream_t stream, const uint32_t **out)
+{
+    *out = nullptr;
+    if (n <= 0) return RT_OK;
+    const uint64_t h = fnv1a(list, (size_t)n * 4);
+    for (const DevList &dl : ctx->dev_lists)
+        if (dl.hash == h && dl.n == n) { *out = dl.d; return RT_OK; }
+    if (ctx->dev_lists.size() >= 64) {
+        /* (hipFree waits for the device: nothing can still be reading the old lists) */
+        for (DevList &dl : ctx->dev_lists) (void)hipFree(dl.d);
+        ctx->dev_lists.clear();
+    }
+    DevList dl;
+    dl.hash = h; dl.n = n;
+    RT_HIP(ctx, hipMalloc((void **)&dl.d, (size_t)n * 4), "allocating a tile list");
+    hipError_t e = hipMemcpyAsync(dl.d, list, (size_t)n * 4, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { (void)hipFree(dl.d); return hip_fail(ctx, e, "uploading a tile list"); }
+    ctx->dev_lists.push_back(dl);
+    *out = dl.d;
     return RT_OK;
+}
+
+rt_status grow(rt_ctx *ctx, float **buf, size_t *cap, size_t need, const char *what)
+{
+    if (*cap >= need && *buf) return RT_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *cap = 0;
+    RT_HIP(ctx, hipMalloc((void **)buf, (need ? need : 4) * 4), what);
+    *cap = need;
+    return RT_OK;
+}
+
+rt_status grow_u32(rt_ctx *ctx, uint32_t **buf, size_t *cap, size_t need, const char *what)
+{
+    if (*cap >= need && *buf) return RT_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *cap = 0;
+    RT_HIP(ctx, hipMalloc((void **)buf, (need ? need : 1) * 4), what);
+    *cap = need;
+    return RT_OK;
+}
+
+int batch_cap(const rt_ctx *ctx, size_t plane_floats)
+{
+    const size_t plane_bytes = plane_floats * 4;
+    if (plane_bytes == 0 || ctx->total_mem == 0) return RT_MAX_BATCH_FRAMES;
+    const size_t k = (ctx->total_mem / 4) / plane_bytes;
+    return k >= RT_MAX_BATCH_FRAMES ? RT_MAX_BATCH_FRAMES : (k < 1 ? 1 : (int)k);
 }
 
 }  // namespace
 
-extern "C" const char *rt_version(void) { return "ray-tracer_amd 0.1 (gfx950)"; }
+extern "C" const char *rt_version(void) { return "ray-tracer_amd 0.3 (gfx950)"; }
 
 extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
 {
@@ -151,6 +233,7 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return RT_ERR_NO_DEVICE; }
     ctx->num_cus = prop.multiProcessorCount;
+    ctx->total_mem = prop.totalGlobalMem;
     if (const char *e = getenv("RT_AMD_WORK_THRESHOLD")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->work_threshold = v; }
     if (const char *e = getenv("RT_AMD_DESCEND_KEEP")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->descend_keep = v; }
     if (const char *e = getenv("RT_AMD_TILE_SCATTER")) ctx->tile_scatter = atoi(e) != 0;
@@ -162,10 +245,6 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (const char *e = getenv("RT_AMD_HIT_LOW")) { int v = atoi(e); if (v >= 0 && v <= 65) ctx->hit_low = v; }
     if (const char *e = getenv("RT_AMD_MIX_BREAK")) { int v = atoi(e); if (v >= 0 && v <= 130) ctx->mix_break = v; }
     if (const char *e = getenv("RT_AMD_SHADE_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->shade_batch = v; }
-    if (const char *e = getenv("RT_AMD_POOL")) ctx->use_pool = atoi(e) != 0;
-    if (const char *e = getenv("RT_AMD_POOL_FILL")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->pool_fill = v; }
-    if (const char *e = getenv("RT_AMD_POOL_LOW")) { int v = atoi(e); if (v >= 0 && v <= 64) ctx->pool_low = v; }
-    if (const char *e = getenv("RT_AMD_POOL_LEAF_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->pool_leaf_batch = v; }
     if (const char *e = getenv("RT_AMD_READY_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->ready_break = v; }
     if (hipMalloc((void **)&ctx->tile_counter, 1024) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
@@ -188,7 +267,11 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     if (ctx->d_job_order) (void)hipFree(ctx->d_job_order);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
     if (ctx->d_bands) (void)hipFree(ctx->d_bands);
-    if (ctx->d_stage) (void)hipFree(ctx->d_stage);
+    for (DevList &dl : ctx->dev_lists) (void)hipFree(dl.d);
+    for (auto &kv : ctx->stages) {
+        if (kv.second.d) (void)hipFree(kv.second.d);
+        if (kv.second.ev_free) (void)hipEventDestroy(kv.second.ev_free);
+    }
     if (ctx->multi_stream) (void)hipStreamDestroy(ctx->multi_stream);
     if (ctx->ev_multi) (void)hipEventDestroy(ctx->ev_multi);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
@@ -214,7 +297,6 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
     const size_t blob_bytes = s->flat.blob.size() * sizeof(rt_f4);
     /* one spare stack entry: the traversal loop always writes the slot above the top */
     const size_t per_thread = s->flat.has_mesh ? (size_t)(s->flat.stack_entries + 1) * 8 : 0;
-    const int candidates[4] = {1024, 768, 512, 256};
     s->threads = 0;
     (void)hipSetDevice(ctx->device);
     if (!s->flat.has_mesh) {
@@ -235,6 +317,10 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
         int best_waves = 0;
         const int mesh_candidates[4] = {1024, 768, 512, 256};
         const char *force_nt = getenv("RT_AMD_THREADS");            /* development: force the workgroup size */
+        if (force_nt) {
+            const int v = atoi(force_nt);
+            if (v != 256 && v != 512 && v != 768 && v != 1024) { delete s; return set_err(ctx, RT_ERR_INVALID, "RT_AMD_THREADS must be 256, 512, 768 or 1024"); }
+        }
         for (int nt : mesh_candidates) {
             if (force_nt && atoi(force_nt) != nt) continue;
             const size_t lds = blob_bytes + per_thread * (size_t)nt;
@@ -245,24 +331,7 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
             if (nb * (nt / 64) > best_waves) { best_waves = nb * (nt / 64); s->threads = nt; s->lds_bytes = lds; s->blocks_per_cu = nb; }
         }
     }
-    /* pooled kernel: 48-byte ray record + 2-byte stack levels per thread, two queues, control words */
-    const size_t pool_per_thread = 48 + (size_t)(s->flat.stack_entries + 1) * 2;
-    const size_t pool_fixed = 2 * 1024 * 4 + 64;
-    const bool pool_ok = ctx->use_pool && s->flat.has_mesh && s->flat.stack_entries <= 30 && s->flat.num_nodes < 65536;
-    if (pool_ok) {
-        s->threads = 0;
-        for (int nt : candidates) {
-            if (blob_bytes + pool_fixed + pool_per_thread * (size_t)nt <= RT_LDS_LIMIT) { s->threads = nt; s->lds_bytes = blob_bytes + pool_fixed + pool_per_thread * (size_t)nt; break; }
-        }
-        s->pool = 1;
-    }
     s->scene_in_lds = 1;
-    if (s->threads == 0 && s->pool) {
-        s->scene_in_lds = 0;
-        s->threads = 1024;
-        s->lds_bytes = pool_fixed + pool_per_thread * 1024;
-        if (s->lds_bytes > RT_LDS_LIMIT) { s->pool = 0; s->scene_in_lds = 1; }
-    }
     if (s->threads == 0) {
         /* larger than a CU's LDS: the kernel reads the scene from global memory (L2-resident),
          * LDS holds only the traversal stacks */
@@ -273,17 +342,15 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
             delete s;
             return set_err(ctx, RT_ERR_UNSUPPORTED, "BVH too deep for the per-lane LDS traversal stack");
         }
-    }
-    if (!s->pool && !s->scene_in_lds) {
         /* (a 256-thread workgroup is admitted at most 6 times at this kernel's SGPR count, whatever the API says:
          * MI355X_MICROARCH.md, residency; surplus workgroups would only queue behind the resident ones) */
-        int nb = rt_kernel_blocks_per_cu(s->flat.has_mesh ? 1 : 0, s->scene_in_lds, s->threads, s->lds_bytes);
+        int nb = rt_kernel_blocks_per_cu(s->flat.has_mesh ? 1 : 0, 0, s->threads, s->lds_bytes);
         s->blocks_per_cu = nb < 1 ? 1 : (nb > RT_MAX_BLOCKS_PER_CU ? RT_MAX_BLOCKS_PER_CU : nb);
     }
-    if (s->pool) s->blocks_per_cu = 1;
     if (const char *e = getenv("RT_AMD_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) s->blocks_per_cu = v; }
+    /* the occupancy probes above discard their errors: a failed probe must not surface later as a launch error */
+    (void)hipGetLastError();
 
-    (void)hipSetDevice(ctx->device);
     hipError_t e = hipMalloc((void **)&s->d_blob, blob_bytes > 0 ? blob_bytes : 16);
     if (e == hipSuccess && blob_bytes) e = hipMemcpy(s->d_blob, s->flat.blob.data(), blob_bytes, hipMemcpyHostToDevice);
     const size_t obj_bytes = s->flat.objects.size() * sizeof(rt_object);
@@ -338,6 +405,39 @@ extern "C" int32_t rt_tile_owned_rows(const rt_tile_spec *t, int32_t height)
     return owned * t->band_rows;
 }
 
+extern "C" int32_t rt_max_batch_frames(rt_ctx *ctx, int32_t width, int32_t height)
+{
+    if (!ctx || width <= 0 || height <= 0) return 1;
+    return batch_cap(ctx, (size_t)width * (size_t)height * 3);
+}
+
+/* Longest-processing-time-first ownership (see include/rt_amd.h) */
+extern "C" rt_status rt_partition_tiles(const uint32_t *cost, int32_t tiles_x, int32_t tiles_y, int32_t n_ranks, int32_t *owner)
+{
+    if (!owner || tiles_x <= 0 || tiles_y <= 0 || n_ranks <= 0 || (int64_t)tiles_x * tiles_y > (int64_t)RT_JOB_TILE_MASK + 1) return RT_ERR_INVALID;
+    const int n = tiles_x * tiles_y;
+    if (!cost) {
+        for (int ty = 0; ty < tiles_y; ty++)
+            for (int tx = 0; tx < tiles_x; tx++) owner[ty * tiles_x + tx] = (tx + ty) % n_ranks;
+        return RT_OK;
+    }
+    std::vector<uint32_t> idx((size_t)n);
+    for (int i = 0; i < n; i++) idx[(size_t)i] = (uint32_t)i;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+    /* (load, rank): the least loaded rank first, the lower rank on a tie */
+    typedef std::pair<uint64_t, int> LR;
+    std::priority_queue<LR, std::vector<LR>, std::greater<LR>> heap;
+    for (int r = 0; r < n_ranks; r++) heap.push(LR(0, r));
+    for (uint32_t t : idx) {
+        LR top = heap.top();
+        heap.pop();
+        owner[t] = top.second;
+        top.first += cost[t];
+        heap.push(top);
+    }
+    return RT_OK;
+}
+
 /* persistent waves: enough workgroups to fill the chip, each wave pulls 8x8 tiles */
 static int launch_blocks(const rt_ctx *ctx, const rt_scene *scene, int num_tiles)
 {
@@ -369,6 +469,58 @@ static void build_job_order(const std::vector<uint32_t> &order, const std::vecto
         for (uint32_t t : order) if (!taken[t]) jobs.push_back(t | (f << RT_JOB_FRAME_SHIFT));
 }
 
+namespace {
+
+uint32_t gcd_u32(uint32_t x, uint32_t y) { while (y) { uint32_t t = x % y; x = y; y = t; } return x; }
+
+/* a stride near n / golden ratio, made coprime to n */
+uint32_t coprime_stride(uint32_t n)
+{
+    if (n <= 2u) return 1u;
+    uint32_t st = (uint32_t)(n * 0.6180339887) | 1u;
+    while (gcd_u32(st, n) != 1u) st += 2u;
+    return st % n ? st % n : 1u;
+}
+
+/* The view's measured costs are on the device (cost_state 1): bring them to the host on `stream` (one
+ * synchronisation), and, when the view uses a tile order, move the `heavy_top` most expensive tiles to its front. */
+rt_status read_costs_and_refine(rt_ctx *ctx, hipStream_t stream)
+{
+    const uint32_t n = (uint32_t)ctx->tiles_host.size();
+    if (ctx->cost_state == 1) {
+        /* on the launch stream: the launch that collected the costs ran on it (or this stream has been ordered
+         * behind it), and a blocking copy on the null stream would not wait for a non-blocking stream's kernel */
+        std::vector<uint32_t> cost(n);
+        RT_HIP(ctx, hipMemcpyAsync(cost.data(), ctx->d_tile_cost, (size_t)n * 4, hipMemcpyDeviceToHost, stream), "reading tile costs");
+        RT_HIP(ctx, hipStreamSynchronize(stream), "reading tile costs");
+        ctx->cost_host.swap(cost);
+    }
+    if (ctx->use_order && ctx->heavy_top > 0) {
+        const std::vector<uint32_t> &cost = ctx->cost_host;
+        std::vector<uint32_t> idx(ctx->order_host);
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+        uint32_t top = (uint32_t)ctx->heavy_top < n ? (uint32_t)ctx->heavy_top : n;
+        while (top > 0 && cost[idx[top - 1]] == 0) top--;
+        std::vector<char> taken(n, 0);
+        std::vector<uint32_t> merged;
+        merged.reserve(n);
+        const uint32_t st = ctx->tile_scatter ? coprime_stride(top) : 1u;
+        for (uint32_t i = 0; i < top; i++) { const uint32_t t = idx[(size_t)(((uint64_t)i * st) % top)]; merged.push_back(t); taken[t] = 1; }
+        for (uint32_t t : ctx->order_host) if (!taken[t]) merged.push_back(t);
+        /* nothing may still be indexing the old order: the stream was synchronised above, or (caller-supplied costs)
+         * the order has not been used by a launch yet */
+        RT_HIP(ctx, hipMemcpyAsync(ctx->d_tile_order, merged.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream), "uploading tile order");
+        RT_HIP(ctx, hipStreamSynchronize(stream), "uploading tile order");     /* `merged` is a local */
+        ctx->order_host.swap(merged);
+        ctx->order_num_heavy = (int)top;
+    }
+    ctx->cost_state = 2;
+    ctx->job_frames = 0;                    /* any uploaded schedule is for another view */
+    return RT_OK;
+}
+
+}  // namespace
+
 /* one launch rendering n_frames consecutive progressive frames (n_frames == 1: a plain frame with an
  * optional separate previous frame; > 1: d_out is updated in place) */
 static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
@@ -380,10 +532,19 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
     if (cam->width <= 0 || cam->height <= 0 || cam->width > 32768 || cam->height > 32768 || (int64_t)cam->width * cam->height > (1 << 28))
         return set_err(ctx, RT_ERR_INVALID, "bad image size (at most 32768 pixels on a side and 2^28 in all)");
     if (rs->rays_per_pixel < 0 || rs->reflection_limit < 0) return set_err(ctx, RT_ERR_INVALID, "bad render settings");
-    rt_tile_spec full = {8, 0, 1, 0};
+    rt_tile_spec full;
+    std::memset(&full, 0, sizeof full);
+    full.band_rows = 8; full.band_stride = 1;
     const rt_tile_spec *t = tiles ? tiles : &full;
-    if (t->band_rows <= 0 || (t->band_rows & 7) || t->band_stride <= 0 || t->band_first < 0 || t->band_first >= t->band_stride)
-        return set_err(ctx, RT_ERR_INVALID, "bad tile spec (band_rows must be a positive multiple of 8, 0 <= band_first < band_stride)");
+    const bool listed = t->tile_list != nullptr;
+    const int tiles_x = (cam->width + 7) / 8, tiles_y = (cam->height + 7) / 8;
+    if (listed) {
+        if (t->num_tiles < 0 || t->num_tiles > tiles_x * tiles_y) return set_err(ctx, RT_ERR_INVALID, "bad tile spec (num_tiles)");
+    } else {
+        if (t->tile_cost) return set_err(ctx, RT_ERR_INVALID, "bad tile spec (tile_cost needs a tile_list)");
+        if (t->band_rows <= 0 || (t->band_rows & 7) || t->band_stride <= 0 || t->band_first < 0 || t->band_first >= t->band_stride)
+            return set_err(ctx, RT_ERR_INVALID, "bad tile spec (band_rows must be a positive multiple of 8, 0 <= band_first < band_stride)");
+    }
     hipStream_t stream = (hipStream_t)hip_stream;
     RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
     /* one launch in flight per context: the scratch is shared (see rt_ctx) */
@@ -404,41 +565,65 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
     for (int i = 0; i < n_frames; i++) a.seeds[i] = (uint32_t)times_ms[i] * 6291469u;       /* src/raytracer.cu:127 */
     a.num_frames = n_frames;
     a.frame_num = frame_num;
-    a.band_rows = t->band_rows;
-    a.band_first = t->band_first;
-    a.band_stride = t->band_stride;
+    a.band_rows = listed ? 8 : t->band_rows;
+    a.band_first = listed ? 0 : t->band_first;
+    a.band_stride = listed ? 1 : t->band_stride;
     a.compact = t->compact ? 1 : 0;
-    a.tiles_x = (cam->width + 7) / 8;
-    const int owned_rows = rt_tile_owned_rows(t, cam->height);
-    a.num_tiles = (owned_rows / 8) * a.tiles_x;
-    {
-        /* a stride near num_tiles / golden ratio, made coprime to num_tiles */
-        auto gcd = [](uint32_t x, uint32_t y) { while (y) { uint32_t t = x % y; x = y; y = t; } return x; };
-        auto coprime_stride = [&](uint32_t n) {
-            if (n <= 2u) return 1u;
-            uint32_t st = (uint32_t)(n * 0.6180339887) | 1u;
-            while (gcd(st, n) != 1u) st += 2u;
-            return st % n ? st % n : 1u;
-        };
-        const uint32_t n = a.num_tiles > 0 ? (uint32_t)a.num_tiles : 1u;
-        a.tile_stride = ctx->tile_scatter ? coprime_stride(n) : 1u;
-        a.tile_order = nullptr;
-        if (ctx->heavy_first && scene->flat.num_meshes > 0 && a.num_tiles > 1) {
-            /* longest-job-first: tiles whose centre ray enters a mesh root box are handed out
-             * first.  Host float math, a heuristic only: any order renders the same image. */
-            std::vector<uint32_t> key;
-            key.push_back(scene->uid); key.push_back((uint32_t)ctx->tile_scatter);
-            for (int i = 0; i < 12; i++) { uint32_t u; std::memcpy(&u, &a.cam[i], 4); key.push_back(u); }
-            key.push_back((uint32_t)a.width); key.push_back((uint32_t)a.height);
+    a.tiles_x = tiles_x;
+    const int owned_rows = listed ? 0 : rt_tile_owned_rows(t, cam->height);
+    a.num_tiles = listed ? t->num_tiles : (owned_rows / 8) * a.tiles_x;
+    const uint32_t n = a.num_tiles > 0 ? (uint32_t)a.num_tiles : 0u;
+    a.tile_stride = ctx->tile_scatter ? coprime_stride(n ? n : 1u) : 1u;
+
+    /* ---- the view: which tiles, in which order, at what cost ---------------------------------------- */
+    bool collecting = false;
+    if (n > 0) {
+        std::vector<uint32_t> key;
+        key.push_back(scene->uid); key.push_back((uint32_t)ctx->tile_scatter);
+        for (int i = 0; i < 12; i++) { uint32_t u; std::memcpy(&u, &a.cam[i], 4); key.push_back(u); }
+        key.push_back((uint32_t)a.width); key.push_back((uint32_t)a.height);
+        if (listed) {
+            uint64_t h = fnv1a(t->tile_list, (size_t)n * 4);
+            if (t->tile_cost) h = fnv1a(t->tile_cost, (size_t)n * 4, h);
+            key.push_back(0xffffffffu); key.push_back(n); key.push_back((uint32_t)h); key.push_back((uint32_t)(h >> 32)); key.push_back(t->tile_cost ? 1u : 0u);
+        } else {
             key.push_back((uint32_t)a.band_rows); key.push_back((uint32_t)a.band_first); key.push_back((uint32_t)a.band_stride);
-            if (key != ctx->order_key || !ctx->d_tile_order) {
-                std::vector<uint32_t> heavy, light;
+        }
+        if (key != ctx->order_key) {
+            /* a new view.  local tile -> tile of the image */
+            std::vector<uint32_t> th(n);
+            if (listed) {
+                std::vector<char> seen((size_t)tiles_x * tiles_y, 0);
+                for (uint32_t i = 0; i < n; i++) {
+                    const uint32_t g = t->tile_list[i];
+                    if (g >= (uint32_t)(tiles_x * tiles_y) || seen[g]) return set_err(ctx, RT_ERR_INVALID, "bad tile spec (a tile index outside the image, or listed twice)");
+                    seen[g] = 1;
+                    th[i] = g;
+                }
+            } else {
                 const int tiles_per_band = a.tiles_x * (a.band_rows >> 3);
-                for (uint32_t t = 0; t < n; t++) {
-                    const int band_local = (int)t / tiles_per_band, in_band = (int)t % tiles_per_band;
+                for (uint32_t i = 0; i < n; i++) {
+                    const int band_local = (int)i / tiles_per_band, in_band = (int)i % tiles_per_band;
                     const int band = a.band_first + band_local * a.band_stride;
-                    const int ty = in_band / a.tiles_x, tx = in_band % a.tiles_x;
-                    const float px = tx * 8 + 4.0f, py = band * a.band_rows + ty * 8 + 4.0f;
+                    th[i] = (uint32_t)((band * (a.band_rows >> 3) + in_band / a.tiles_x) * a.tiles_x + in_band % a.tiles_x);
+                }
+            }
+            ctx->order_key.clear();              /* (until everything below has succeeded) */
+            ctx->tiles_host.swap(th);
+            ctx->cost_state = 0;
+            ctx->cost_host.clear();
+            ctx->order_num_heavy = 0;
+            ctx->job_frames = 0;
+            rt_status st;
+            if ((st = grow_u32(ctx, &ctx->d_tile_cost, &ctx->tile_cost_cap, n, "allocating tile costs")) != RT_OK) return st;
+            ctx->use_order = ctx->heavy_first && scene->flat.num_meshes > 0 && n > 1;
+            if (ctx->use_order) {
+                /* longest-job-first, first guess: tiles whose centre ray enters a mesh root box are handed out
+                 * first.  Host float math, a heuristic only: any order renders the same image. */
+                std::vector<uint32_t> heavy, light;
+                for (uint32_t i = 0; i < n; i++) {
+                    const int ty = (int)(ctx->tiles_host[i] / (uint32_t)a.tiles_x), tx = (int)(ctx->tiles_host[i] % (uint32_t)a.tiles_x);
+                    const float px = tx * 8 + 4.0f, py = ty * 8 + 4.0f;
                     float d[3], o[3];
                     for (int k = 0; k < 3; k++) { o[k] = a.cam[k]; d[k] = a.cam[3 + k] + a.cam[6 + k] * px + a.cam[9 + k] * py - o[k]; }
                     bool hit = false;
@@ -457,68 +642,44 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
                         }
                         hit = tmin <= tmax;
                     }
-                    (hit ? heavy : light).push_back(t);
+                    (hit ? heavy : light).push_back(i);
                 }
                 std::vector<uint32_t> order;
                 order.reserve(n);
                 for (const std::vector<uint32_t> *cls : {&heavy, &light}) {
                     const uint32_t m = (uint32_t)cls->size();
-                    const uint32_t st = ctx->tile_scatter ? coprime_stride(m) : 1u;
-                    for (uint32_t i = 0; i < m; i++) order.push_back((*cls)[(size_t)(((uint64_t)i * st) % m)]);
+                    const uint32_t st2 = ctx->tile_scatter ? coprime_stride(m) : 1u;
+                    for (uint32_t i = 0; i < m; i++) order.push_back((*cls)[(size_t)(((uint64_t)i * st2) % m)]);
                 }
-                if (ctx->tile_order_cap < n) {
-                    if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
-                    if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
-                    ctx->d_tile_order = ctx->d_tile_cost = nullptr;
-                    ctx->tile_order_cap = 0;
-                    RT_HIP(ctx, hipMalloc((void **)&ctx->d_tile_order, (size_t)n * 4), "allocating tile order");
-                    RT_HIP(ctx, hipMalloc((void **)&ctx->d_tile_cost, (size_t)n * 4), "allocating tile costs");
-                    ctx->tile_order_cap = n;
-                }
+                if ((st = grow_u32(ctx, &ctx->d_tile_order, &ctx->tile_order_cap, n, "allocating tile order")) != RT_OK) return st;
                 RT_HIP(ctx, hipMemcpyAsync(ctx->d_tile_order, order.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream), "uploading tile order");
                 RT_HIP(ctx, hipStreamSynchronize(stream), "uploading tile order");     /* `order` is a local */
-                ctx->order_key = key;
                 ctx->order_host.swap(order);
-                ctx->order_num_heavy = 0;
-                ctx->cost_state = 0;
-                ctx->job_frames = 0;
             }
-            /* The guess above is refined once per view with what the tiles really cost: the first
-             * launch of a view also adds up, per tile, the traversal steps of its pixels; the second
-             * reads them back (one synchronisation) and moves the `heavy_top` most expensive tiles to
-             * the front, most expensive first within rounds of one ticket per wave.  In a multi-frame
-             * launch those tiles go first for ALL frames (see px_fetch): with the true costs that is
-             * worth 10 % at three frames per launch (with the guess, nothing). */
-            if (ctx->cost_state == 0 && ctx->heavy_top > 0) {
-                RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)n * 4, stream), "clearing tile costs");
-                a.tile_cost = ctx->d_tile_cost;
-                ctx->cost_state = 1;
-            } else if (ctx->cost_state == 1) {
-                /* on the launch stream: the launch that collected the costs ran on it (or this stream has
-                 * been ordered behind it above), and a blocking copy on the null stream would not wait for
-                 * a non-blocking stream's kernel */
-                std::vector<uint32_t> cost(n);
-                RT_HIP(ctx, hipMemcpyAsync(cost.data(), ctx->d_tile_cost, (size_t)n * 4, hipMemcpyDeviceToHost, stream), "reading tile costs");
-                RT_HIP(ctx, hipStreamSynchronize(stream), "reading tile costs");
-                std::vector<uint32_t> idx(ctx->order_host);
-                std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
-                uint32_t top = (uint32_t)ctx->heavy_top < n ? (uint32_t)ctx->heavy_top : n;
-                while (top > 0 && cost[idx[top - 1]] == 0) top--;
-                std::vector<char> taken(n, 0);
-                std::vector<uint32_t> merged;
-                merged.reserve(n);
-                const uint32_t st = ctx->tile_scatter ? coprime_stride(top) : 1u;
-                for (uint32_t i = 0; i < top; i++) { const uint32_t t = idx[(size_t)(((uint64_t)i * st) % top)]; merged.push_back(t); taken[t] = 1; }
-                for (uint32_t t : ctx->order_host) if (!taken[t]) merged.push_back(t);
-                /* the stream is idle (synchronised above): nothing is indexing the old order any more */
-                RT_HIP(ctx, hipMemcpyAsync(ctx->d_tile_order, merged.data(), (size_t)n * 4, hipMemcpyHostToDevice, stream), "uploading tile order");
-                RT_HIP(ctx, hipStreamSynchronize(stream), "uploading tile order");     /* `merged` is a local */
-                ctx->order_host.swap(merged);
-                ctx->order_num_heavy = (int)top;
-                ctx->cost_state = 2;
-                ctx->cost_host.swap(cost);
-                ctx->job_frames = 0;                    /* any uploaded schedule is for another view */
+            if (listed && t->tile_cost) {
+                /* the caller knows what the tiles cost (an earlier launch of the view, possibly on other GPUs) */
+                ctx->cost_host.assign(t->tile_cost, t->tile_cost + n);
+                if ((st = read_costs_and_refine(ctx, stream)) != RT_OK) return st;
             }
+            ctx->order_key = key;
+        }
+        if (listed) {
+            rt_status st = device_tile_list(ctx, t->tile_list, (int)n, stream, &a.tile_list);
+            if (st != RT_OK) return st;
+        }
+        /* The first launch of a view adds up, per tile, the work of its pixels; the second reads the sums back (one
+         * synchronisation) and moves the `heavy_top` most expensive tiles to the front of the order, most expensive
+         * first within rounds of one ticket per wave.  In a multi-frame launch those tiles go first for ALL frames
+         * (see px_fetch): with the true costs that is worth 10 % at three frames per launch (with the guess, nothing). */
+        if (ctx->cost_state == 0) {
+            RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)n * 4, stream), "clearing tile costs");
+            a.tile_cost = ctx->d_tile_cost;
+            collecting = true;
+        } else if (ctx->cost_state == 1 && ctx->use_order) {
+            rt_status st = read_costs_and_refine(ctx, stream);
+            if (st != RT_OK) return st;
+        }
+        if (ctx->use_order) {
             a.num_heavy_tiles = (ctx->cost_state == 2 && n_frames > 1) ? ctx->order_num_heavy : 0;
             a.tile_order = ctx->d_tile_order;
             /* Multi-frame launch of a view whose tile costs are known: the host lays out the whole schedule.
@@ -526,22 +687,17 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
              * cannot be split and the launch is at least as long as its longest job - which therefore has to
              * start at once, for EVERY frame (frames only meet in the blend behind the kernel).  Longest
              * processing time first: jobs in order of decreasing measured tile cost, all frames of a tile
-             * together; tiles that cost nothing (no ray enters a mesh) follow frame by frame.  Consecutive
-             * tickets are also similar in cost, so the lanes a wave refills as its cheap pixels finish
-             * collect pixels of one kind.  Any schedule renders the same image.  (Measured, 20 frames of the
-             * monkey configuration: +6 % on one GPU and +25 % on the share one of 8 GPUs renders, against
-             * "the 1,024 most expensive tiles of frame 0, of frame 1, ... first"; dealing the first round out
-             * so that a workgroup's 16 waves get 16 different cost strata changed nothing.) */
+             * together; tiles that cost nothing follow frame by frame.  Consecutive tickets are also similar
+             * in cost, so the lanes a wave refills as its cheap pixels finish collect pixels of one kind.  Any
+             * schedule renders the same image.  (Measured, 20 frames of the monkey configuration: +6 % on one
+             * GPU and +25 % on the share one of 8 GPUs renders, against "the 1,024 most expensive tiles of frame
+             * 0, of frame 1, ... first".) */
             if (ctx->lpt && ctx->cost_state == 2 && n_frames > 1 && n <= (RT_JOB_TILE_MASK + 1u) && ctx->cost_host.size() == n) {
                 if (ctx->job_frames != n_frames) {
                     std::vector<uint32_t> jobs;
                     build_job_order(ctx->order_host, ctx->cost_host, (uint32_t)ctx->lpt_top, (uint32_t)n_frames, jobs);
-                    if (ctx->job_cap < jobs.size()) {
-                        if (ctx->d_job_order) (void)hipFree(ctx->d_job_order);
-                        ctx->d_job_order = nullptr; ctx->job_cap = 0;
-                        RT_HIP(ctx, hipMalloc((void **)&ctx->d_job_order, jobs.size() * 4), "allocating the launch schedule");
-                        ctx->job_cap = jobs.size();
-                    }
+                    rt_status st = grow_u32(ctx, &ctx->d_job_order, &ctx->job_cap, jobs.size(), "allocating the launch schedule");
+                    if (st != RT_OK) return st;
                     RT_HIP(ctx, hipMemcpyAsync(ctx->d_job_order, jobs.data(), jobs.size() * 4, hipMemcpyHostToDevice, stream), "uploading the launch schedule");
                     RT_HIP(ctx, hipStreamSynchronize(stream), "uploading the launch schedule");     /* `jobs` is a local */
                     ctx->job_frames = n_frames;
@@ -567,9 +723,6 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
     a.hit_low = ctx->hit_low > 0 && ctx->mix_break > 0 ? ctx->hit_low : ctx->hit_break;
     a.mix_break = ctx->hit_low > 0 && ctx->mix_break > 0 ? ctx->mix_break : 1000;
     a.shade_batch = ctx->shade_batch;
-    a.pool_fill = ctx->pool_fill;
-    a.pool_low = ctx->pool_low;
-    a.pool_leaf_batch = ctx->pool_leaf_batch;
     a.descend_keep = ctx->descend_keep;
     a.tri_uv = scene->d_tri_uv;
     a.tex_data = scene->d_tex;
@@ -580,15 +733,11 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
 
     size_t plane_floats = 0;
     if (in_place) {
-        plane_floats = (size_t)(a.compact ? owned_rows : cam->height) * (size_t)cam->width * 3;
+        plane_floats = a.compact ? (listed ? (size_t)n * 192 : (size_t)owned_rows * (size_t)cam->width * 3)
+                                 : (size_t)cam->height * (size_t)cam->width * 3;
         const size_t need = plane_floats * (size_t)n_frames;
-        if (ctx->partial_cap < need) {
-            if (ctx->d_partial) (void)hipFree(ctx->d_partial);
-            ctx->d_partial = nullptr;
-            ctx->partial_cap = 0;
-            RT_HIP(ctx, hipMalloc((void **)&ctx->d_partial, need * 4), "allocating the per-frame planes of a multi-frame launch");
-            ctx->partial_cap = need;
-        }
+        rt_status st = grow(ctx, &ctx->d_partial, &ctx->partial_cap, need, "allocating the per-frame planes of a multi-frame launch");
+        if (st != RT_OK) return st;
         a.partial = ctx->d_partial;
         a.partial_plane = (int64_t)(plane_floats / 3);
     }
@@ -597,16 +746,17 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
     if (a.num_tiles > 0) {
         const int blocks = launch_blocks(ctx, scene, a.num_tiles);
         RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 512, stream), "clearing tile counter");
-        if (scene->pool)
-            RT_HIP(ctx, rt_launch_render_pool(&a, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
-        else
-            RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
+        RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
+        if (collecting) ctx->cost_state = 1;            /* only now: a failed launch leaves no costs to sort on */
     }
     if (in_place && a.num_tiles > 0) {
-        /* the pixels this launch owns: full layout = its bands inside the frame (other rows stay as they
-         * are only in the compact layout, where the buffer holds nothing else), so fold band by band */
-        if (a.compact || a.band_stride == 1) {
+        /* the pixels this launch owns.  Compact layouts, and a full frame rendered whole: one pass over the buffer;
+         * a full-layout frame of which the launch owns some bands / tiles: only those are folded */
+        if (a.compact || (!listed && a.band_stride == 1)) {
             RT_HIP(ctx, rt_launch_blend(ctx->d_partial, (long long)plane_floats, n_frames, frame_num, d_out, (long long)plane_floats, stream), "launching blend kernel");
+        } else if (listed) {
+            RT_HIP(ctx, rt_launch_blend_tiles(ctx->d_partial, (long long)plane_floats, n_frames, frame_num, d_out, a.tile_list, (int)n, tiles_x, cam->width, cam->height, stream),
+                   "launching blend kernel");
         } else {
             const int bands_total = (cam->height + a.band_rows - 1) / a.band_rows;
             for (int b = a.band_first; b < bands_total; b += a.band_stride) {
@@ -644,6 +794,39 @@ extern "C" rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, 
     return render_frames(ctx, scene, cam, rs, times_ms, n_frames, frame_num, tiles, nullptr, d_frame, hip_stream, true);
 }
 
+extern "C" rt_status rt_tile_costs(rt_ctx *ctx, uint32_t *tile_ids, uint32_t *costs, int32_t capacity, int32_t *count)
+{
+    if (!ctx || !count || capacity < 0 || (capacity > 0 && (!tile_ids || !costs))) return set_err(ctx, RT_ERR_INVALID, "null argument");
+    *count = 0;
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    if (ctx->order_key.empty() || ctx->cost_state == 0) return set_err(ctx, RT_ERR_INVALID, "no launch of the current view has collected tile costs");
+    if (ctx->cost_state == 1) {
+        rt_status st = read_costs_and_refine(ctx, ctx->last_stream);
+        if (st != RT_OK) return st;
+    }
+    const size_t n = ctx->tiles_host.size();
+    if (ctx->cost_host.size() != n) return set_err(ctx, RT_ERR_INVALID, "no launch of the current view has collected tile costs");
+    const size_t m = n < (size_t)capacity ? n : (size_t)capacity;
+    for (size_t i = 0; i < m; i++) { tile_ids[i] = ctx->tiles_host[i]; costs[i] = ctx->cost_host[i]; }
+    *count = (int32_t)n;
+    return RT_OK;
+}
+
+extern "C" rt_status rt_tiles_copy_device(rt_ctx *ctx, float *d_compact, float *d_frame, int32_t width, int32_t height,
+                                          const uint32_t *tile_list, int32_t num_tiles, int32_t to_frame, void *hip_stream)
+{
+    if (!ctx || !d_compact || !d_frame || width <= 0 || height <= 0 || num_tiles < 0 || (num_tiles > 0 && !tile_list)) return set_err(ctx, RT_ERR_INVALID, "bad argument");
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
+    for (int32_t i = 0; i < num_tiles; i++)
+        if (tile_list[i] >= (uint32_t)(tiles_x * tiles_y)) return set_err(ctx, RT_ERR_INVALID, "a tile index outside the image");
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    const uint32_t *d_list = nullptr;
+    rt_status st = device_tile_list(ctx, tile_list, num_tiles, (hipStream_t)hip_stream, &d_list);
+    if (st != RT_OK) return st;
+    RT_HIP(ctx, rt_launch_tiles_copy(d_compact, d_frame, d_list, num_tiles, tiles_x, width, height, to_frame ? 1 : 0, (hipStream_t)hip_stream), "launching the tile copy");
+    return RT_OK;
+}
+
 /* test hook: evaluates one function of rt_math.h / rt_rng.h on the DEVICE for n inputs given
  * and returned as raw 32-bit patterns in host memory */
 extern "C" rt_status rt_debug_eval(rt_ctx *ctx, int32_t op, const uint32_t *in, uint32_t *out, int32_t n)
@@ -678,8 +861,25 @@ extern "C" rt_status rt_last_kernel_ms(rt_ctx *ctx, float *ms)
     if (!ctx->have_timing) return set_err(ctx, RT_ERR_INVALID, "no render has been launched yet");
     RT_HIP(ctx, hipEventSynchronize(ctx->ev_stop), "waiting for render kernel");
     RT_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop), "reading kernel time");
-    return check_kernel_flag(ctx);
+    return RT_OK;
 }
+
+namespace {
+
+rt_status ensure_frame_buffers(rt_ctx *ctx, size_t bytes)
+{
+    if (bytes == ctx->frame_bytes) return RT_OK;
+    if (ctx->d_prev) (void)hipFree(ctx->d_prev);
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    ctx->d_prev = ctx->d_out = nullptr;
+    ctx->frame_bytes = 0;
+    RT_HIP(ctx, hipMalloc((void **)&ctx->d_prev, bytes), "allocating previous-frame buffer");
+    RT_HIP(ctx, hipMalloc((void **)&ctx->d_out, bytes), "allocating frame buffer");
+    ctx->frame_bytes = bytes;
+    return RT_OK;
+}
+
+}  // namespace
 
 extern "C" rt_status rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
                                int32_t time_ms, int32_t *frame_num, float *previous_render)
@@ -688,20 +888,12 @@ extern "C" rt_status rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_came
     if (cam->width <= 0 || cam->height <= 0) return set_err(ctx, RT_ERR_INVALID, "bad image size");
     RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
     const size_t bytes = (size_t)cam->width * (size_t)cam->height * 3 * sizeof(float);
-    if (bytes != ctx->frame_bytes) {
-        if (ctx->d_prev) (void)hipFree(ctx->d_prev);
-        if (ctx->d_out) (void)hipFree(ctx->d_out);
-        ctx->d_prev = ctx->d_out = nullptr;
-        ctx->frame_bytes = 0;
-        RT_HIP(ctx, hipMalloc((void **)&ctx->d_prev, bytes), "allocating previous-frame buffer");
-        RT_HIP(ctx, hipMalloc((void **)&ctx->d_out, bytes), "allocating frame buffer");
-        ctx->frame_bytes = bytes;
-    }
+    rt_status st = ensure_frame_buffers(ctx, bytes);
+    if (st != RT_OK) return st;
     RT_HIP(ctx, hipMemcpy(ctx->d_prev, previous_render, bytes, hipMemcpyHostToDevice), "copying previous frame");
-    rt_status st = rt_render_device(ctx, scene, cam, rs, time_ms, *frame_num, nullptr, ctx->d_prev, ctx->d_out, nullptr);
+    st = rt_render_device(ctx, scene, cam, rs, time_ms, *frame_num, nullptr, ctx->d_prev, ctx->d_out, nullptr);
     if (st != RT_OK) return st;
     RT_HIP(ctx, hipDeviceSynchronize(), "render kernel");
-    if ((st = check_kernel_flag(ctx)) != RT_OK) return st;
     RT_HIP(ctx, hipMemcpy(previous_render, ctx->d_out, bytes, hipMemcpyDeviceToHost), "copying frame to host");
     *frame_num += 1;                                   /* src/dispatch.cu:159 */
     RT_HIP(ctx, hipPeekAtLastError(), "final check after render");   /* src/dispatch.cu:161-162 */
@@ -709,7 +901,7 @@ extern "C" rt_status rt_render(rt_ctx *ctx, const rt_scene *scene, const rt_came
 }
 
 /* the same for n_frames consecutive frames at once (seeds times_ms[i]): one multi-frame launch per
- * 32 frames; *frame_num advances by n_frames */
+ * rt_max_batch_frames frames; *frame_num advances by n_frames */
 extern "C" rt_status rt_render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
                                       const int32_t *times_ms, int32_t n_frames, int32_t *frame_num, float *previous_render)
 {
@@ -717,46 +909,39 @@ extern "C" rt_status rt_render_frames(rt_ctx *ctx, const rt_scene *scene, const 
     if (cam->width <= 0 || cam->height <= 0) return set_err(ctx, RT_ERR_INVALID, "bad image size");
     RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
     const size_t bytes = (size_t)cam->width * (size_t)cam->height * 3 * sizeof(float);
-    if (bytes != ctx->frame_bytes) {
-        if (ctx->d_prev) (void)hipFree(ctx->d_prev);
-        if (ctx->d_out) (void)hipFree(ctx->d_out);
-        ctx->d_prev = ctx->d_out = nullptr;
-        ctx->frame_bytes = 0;
-        RT_HIP(ctx, hipMalloc((void **)&ctx->d_prev, bytes), "allocating previous-frame buffer");
-        RT_HIP(ctx, hipMalloc((void **)&ctx->d_out, bytes), "allocating frame buffer");
-        ctx->frame_bytes = bytes;
-    }
+    rt_status st = ensure_frame_buffers(ctx, bytes);
+    if (st != RT_OK) return st;
     RT_HIP(ctx, hipMemcpy(ctx->d_out, previous_render, bytes, hipMemcpyHostToDevice), "copying previous frame");
+    const int32_t cap = batch_cap(ctx, bytes / 4);
     for (int32_t done = 0; done < n_frames;) {
-        const int32_t k = n_frames - done < RT_MAX_BATCH_FRAMES ? n_frames - done : RT_MAX_BATCH_FRAMES;
-        rt_status st = rt_render_device_batch(ctx, scene, cam, rs, times_ms + done, k, *frame_num + done, nullptr, ctx->d_out, nullptr);
+        const int32_t k = n_frames - done < cap ? n_frames - done : cap;
+        st = rt_render_device_batch(ctx, scene, cam, rs, times_ms + done, k, *frame_num + done, nullptr, ctx->d_out, nullptr);
         if (st != RT_OK) return st;
         done += k;
     }
     RT_HIP(ctx, hipDeviceSynchronize(), "render kernel");
-    rt_status st = check_kernel_flag(ctx);
-    if (st != RT_OK) return st;
     RT_HIP(ctx, hipMemcpy(previous_render, ctx->d_out, bytes, hipMemcpyDeviceToHost), "copying frame to host");
     *frame_num += n_frames;
     RT_HIP(ctx, hipPeekAtLastError(), "final check after render");
     return RT_OK;
 }
 
-/* waits for the most recent launch of this context and reports a frame the pooled kernel gave up on */
+/* waits for the most recent launch of this context */
 extern "C" rt_status rt_ctx_synchronize(rt_ctx *ctx)
 {
     if (!ctx) return RT_ERR_INVALID;
     RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
     if (!ctx->launched) return RT_OK;
     RT_HIP(ctx, hipEventSynchronize(ctx->ev_stop), "waiting for render kernel");
-    return check_kernel_flag(ctx);
+    return RT_OK;
 }
 
 /* =============================================================================================
- * Multi-GPU from one host thread (SURVEY.md §8(b) "rt_gather", §8(e)): rank i of n renders the
- * bands b with b % n == i on its own GPU into a compact band buffer; the bands travel to the
- * root's GPU with one peer copy per rank (xGMI) and are de-interleaved there.  No collective is
- * needed: nothing is reduced, every pixel has one owner.
+ * Multi-GPU from one host thread (SURVEY.md §8(b) "rt_gather", §8(e)): every rank renders the tiles it
+ * owns on its own GPU into a compact buffer; the buffers travel to the root's GPU with one peer copy per
+ * rank (xGMI) and are de-interleaved there.  No collective is needed: nothing is reduced, every pixel has
+ * one owner.  Ownership is either static (bands: rank i owns the bands b % n == i) or cost-balanced (tile
+ * lists dealt longest-processing-time-first from the costs the view's first launch measures).
  * ============================================================================================= */
 namespace {
 
@@ -793,16 +978,6 @@ hipError_t copy_bands(const BandLayout &L, int i, float *full, float *compact, b
     return e;
 }
 
-rt_status grow(rt_ctx *ctx, float **buf, size_t *cap, size_t need, const char *what)
-{
-    if (*cap >= need && *buf) return RT_OK;
-    if (*buf) (void)hipFree(*buf);
-    *buf = nullptr; *cap = 0;
-    RT_HIP(ctx, hipMalloc((void **)buf, (need ? need : 4) * 4), what);
-    *cap = need;
-    return RT_OK;
-}
-
 rt_status multi_prepare(rt_ctx *ctx)
 {
     RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
@@ -820,52 +995,132 @@ hipError_t copy_between(float *dst, int dst_dev, const float *src, int src_dev, 
     return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, stream);
 }
 
+/* The root's landing area for src's compact image, at least `need` floats, ready to be written in the order of `s0`:
+ * s0 has been made to wait for the last de-interleave that read it (which may have been queued on another stream
+ * of the root by an earlier call).  Leaves the root's device current. */
+rt_status stage_for(rt_ctx *root, rt_ctx *src, size_t need, hipStream_t s0, Stage **out)
+{
+    RT_HIP(root, hipSetDevice(root->device), "selecting device");
+    Stage &sg = root->stages[src];
+    if (!sg.ev_free) RT_HIP(root, hipEventCreateWithFlags(&sg.ev_free, hipEventDisableTiming), "creating the staging event");
+    if (sg.cap < need || !sg.d) {
+        /* nothing may still be reading or writing the old area */
+        if (sg.used) RT_HIP(root, hipEventSynchronize(sg.ev_free), "waiting for the staging area");
+        if (src->multi_stream) { (void)hipSetDevice(src->device); (void)hipStreamSynchronize(src->multi_stream); (void)hipSetDevice(root->device); }
+        rt_status st = grow(root, &sg.d, &sg.cap, need, "allocating the gather staging area");
+        if (st != RT_OK) return st;
+        sg.used = false;
+    }
+    if (sg.used) RT_HIP(root, hipStreamWaitEvent(s0, sg.ev_free, 0), "ordering behind the previous de-interleave");
+    *out = &sg;
+    return RT_OK;
+}
+
+int peer_access(rt_ctx *a, rt_ctx *b)
+{
+    if (a->device == b->device) return 1;
+    auto it = a->peer_ok.find(b->device);
+    if (it != a->peer_ok.end()) return it->second;
+    int ok = 1;
+    for (int dir = 0; dir < 2; dir++) {
+        const int from = dir ? b->device : a->device, to = dir ? a->device : b->device;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || !can) { ok = 0; continue; }
+        if (hipSetDevice(from) != hipSuccess) { ok = 0; continue; }
+        const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) ok = 0;
+    }
+    (void)hipGetLastError();           /* "already enabled" must not surface as a later launch error */
+    (void)hipSetDevice(a->device);
+    a->peer_ok[b->device] = ok;
+    b->peer_ok[a->device] = ok;
+    return ok;
+}
+
 }  // namespace
 
-/* The exchange step alone: the compact band buffer `d_bands` of the rank described by `src_tiles`
+extern "C" int32_t rt_peer_access(rt_ctx *a, rt_ctx *b)
+{
+    if (!a || !b) return -RT_ERR_INVALID;
+    return peer_access(a, b);
+}
+
+/* The exchange step alone: the compact buffer `d_bands` of the rank described by `src_tiles`
  * (on src's GPU) lands in the full frame `d_frame` on root's GPU.  Ordered behind src's most recent
  * launch; the frame is complete in `root_stream` order. */
 extern "C" rt_status rt_gather(rt_ctx *root, float *d_frame, int32_t width, int32_t height, rt_ctx *src, const float *d_bands,
                                const rt_tile_spec *src_tiles, void *root_stream)
 {
     if (!root || !src || !d_frame || !d_bands || !src_tiles) return set_err(root, RT_ERR_INVALID, "null argument");
-    if (width <= 0 || height <= 0 || src_tiles->band_rows <= 0 || (src_tiles->band_rows & 7) || src_tiles->band_stride <= 0 ||
-        src_tiles->band_first < 0 || src_tiles->band_first >= src_tiles->band_stride)
-        return set_err(root, RT_ERR_INVALID, "bad tile spec");
+    if (width <= 0 || height <= 0) return set_err(root, RT_ERR_INVALID, "bad image size");
+    const bool listed = src_tiles->tile_list != nullptr;
+    const int tiles_x = (width + 7) / 8, tiles_y = (height + 7) / 8;
     BandLayout L;
-    L.W = width; L.H = height; L.band_rows = src_tiles->band_rows; L.n = src_tiles->band_stride;
-    const int i = src_tiles->band_first;
+    size_t floats;
+    if (listed) {
+        if (src_tiles->num_tiles < 0 || src_tiles->num_tiles > tiles_x * tiles_y) return set_err(root, RT_ERR_INVALID, "bad tile spec");
+        for (int32_t i = 0; i < src_tiles->num_tiles; i++)
+            if (src_tiles->tile_list[i] >= (uint32_t)(tiles_x * tiles_y)) return set_err(root, RT_ERR_INVALID, "a tile index outside the image");
+        floats = (size_t)src_tiles->num_tiles * 192;
+    } else {
+        if (src_tiles->band_rows <= 0 || (src_tiles->band_rows & 7) || src_tiles->band_stride <= 0 ||
+            src_tiles->band_first < 0 || src_tiles->band_first >= src_tiles->band_stride)
+            return set_err(root, RT_ERR_INVALID, "bad tile spec");
+        L.W = width; L.H = height; L.band_rows = src_tiles->band_rows; L.n = src_tiles->band_stride;
+        floats = L.floats_of(src_tiles->band_first);
+    }
     rt_status st = multi_prepare(root);
     if (st != RT_OK) return st;
     hipStream_t s0 = (hipStream_t)root_stream;
-    const float *from = d_bands;
+    float *from = const_cast<float *>(d_bands);
+    Stage *sg = nullptr;
     if (src->device != root->device) {
-        /* one peer copy of the whole band buffer into the root's staging area, behind src's last launch */
-        size_t off = 0;
-        for (int r = 0; r < i; r++) off += L.floats_of(r);
-        size_t total = off;
-        for (int r = i; r < L.n; r++) total += L.floats_of(r);
-        if (root->stage_cap < total) {
-            RT_HIP(root, hipStreamSynchronize(s0), "waiting for the staging area");
-            if ((st = grow(root, &root->d_stage, &root->stage_cap, total, "allocating the gather staging area")) != RT_OK) return st;
-        }
-        if ((st = multi_prepare(src)) != RT_OK) return st;
+        /* one peer copy of the whole compact buffer into the root's staging area for this source: behind src's last
+         * launch, and behind the de-interleave of the PREVIOUS gather from this source, which reads the same area on the
+         * root's stream (src may be a frame ahead of the root) */
+        if ((st = multi_prepare(src)) != RT_OK) return set_err(root, st, rt_last_error(src));
+        (void)peer_access(src, root);
+        if ((st = stage_for(root, src, floats, s0, &sg)) != RT_OK) return st;
+        RT_HIP(src, hipSetDevice(src->device), "selecting device");
+        if (sg->used) RT_HIP(src, hipStreamWaitEvent(src->multi_stream, sg->ev_free, 0), "ordering the copy behind the previous de-interleave");
         if (src->launched) RT_HIP(src, hipStreamWaitEvent(src->multi_stream, src->ev_stop, 0), "ordering the gather behind the render");
-        RT_HIP(src, copy_between(root->d_stage + off, root->device, d_bands, src->device, L.floats_of(i) * 4, src->multi_stream), "copying bands to the root GPU");
+        RT_HIP(src, copy_between(sg->d, root->device, d_bands, src->device, floats * 4, src->multi_stream), "copying the rank's image to the root GPU");
         RT_HIP(src, hipEventRecord(src->ev_multi, src->multi_stream), "recording the gather event");
         RT_HIP(root, hipSetDevice(root->device), "selecting device");
         RT_HIP(root, hipStreamWaitEvent(s0, src->ev_multi, 0), "ordering the de-interleave behind the copy");
-        from = root->d_stage + off;
-    } else if (src->launched) {
-        RT_HIP(root, hipStreamWaitEvent(s0, src->ev_stop, 0), "ordering the gather behind the render");
+        from = sg->d;
+    } else {
+        RT_HIP(root, hipSetDevice(root->device), "selecting device");
+        if (src->launched) RT_HIP(root, hipStreamWaitEvent(s0, src->ev_stop, 0), "ordering the gather behind the render");
     }
-    RT_HIP(root, copy_bands(L, i, d_frame, const_cast<float *>(from), true, s0), "de-interleaving bands");
+    if (listed) {
+        const uint32_t *d_list = nullptr;
+        if ((st = device_tile_list(root, src_tiles->tile_list, src_tiles->num_tiles, s0, &d_list)) != RT_OK) return st;
+        RT_HIP(root, rt_launch_tiles_copy(from, d_frame, d_list, src_tiles->num_tiles, tiles_x, width, height, 1, s0), "de-interleaving tiles");
+    } else {
+        RT_HIP(root, copy_bands(L, src_tiles->band_first, d_frame, from, true, s0), "de-interleaving bands");
+    }
+    if (sg) {
+        RT_HIP(root, hipEventRecord(sg->ev_free, s0), "recording the staging event");
+        sg->used = true;
+    }
     return RT_OK;
 }
 
+namespace {
+
+/* what rank i of a multi-GPU call renders and where its image lives */
+struct RankPlan {
+    rt_tile_spec spec;
+    size_t floats = 0;                   /* size of its compact image */
+    const uint32_t *root_list = nullptr; /* tile lists: the rank's list on the ROOT's GPU (for the copies to and from the frame) */
+};
+
+}  // namespace
+
 /* n_frames consecutive progressive frames over n_ranks GPUs, accumulated in place in d_frame (a full
  * frame on ranks[0]'s GPU).  Replaces run_ray_tracer src/dispatch.cu:127-153 for a node: what one
- * device did there, n do here, each for the bands it owns. */
+ * device did there, n do here, each for the tiles it owns. */
 extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_ranks, const rt_camera *cam, const rt_render_settings *rs,
                                             const int32_t *times_ms, int32_t n_frames, int32_t frame_num, int32_t band_rows,
                                             float *d_frame, void *hip_stream)
@@ -873,81 +1128,156 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
     if (!ranks || n_ranks < 1 || !ranks[0].ctx) return RT_ERR_INVALID;
     rt_ctx *root = ranks[0].ctx;
     if (!cam || !rs || !times_ms || !d_frame || n_frames < 1 || frame_num < 0) return set_err(root, RT_ERR_INVALID, "null argument");
-    if (cam->width <= 0 || cam->height <= 0 || band_rows <= 0 || (band_rows & 7)) return set_err(root, RT_ERR_INVALID, "bad image size or band_rows (a positive multiple of 8)");
+    if (cam->width <= 0 || cam->height <= 0 || band_rows < 0 || (band_rows & 7)) return set_err(root, RT_ERR_INVALID, "bad image size or band_rows (0, or a positive multiple of 8)");
     for (int i = 0; i < n_ranks; i++) {
         if (!ranks[i].ctx || !ranks[i].scene || ranks[i].scene->ctx != ranks[i].ctx) return set_err(root, RT_ERR_INVALID, "rank without a context, or a scene committed on another context");
         for (int j = 0; j < i; j++) if (ranks[j].ctx == ranks[i].ctx) return set_err(root, RT_ERR_INVALID, "a context may appear once (its launch scratch is not shared between ranks)");
     }
-    BandLayout L;
-    L.W = cam->width; L.H = cam->height; L.band_rows = band_rows; L.n = n_ranks;
+    const int W = cam->width, H = cam->height;
+    const int tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
+    const bool listed = band_rows == 0;
     hipStream_t s0 = (hipStream_t)hip_stream;
     rt_status st;
-    size_t total = 0;
-    std::vector<size_t> off(n_ranks);
-    for (int i = 0; i < n_ranks; i++) { off[i] = total; total += L.floats_of(i); }
     if ((st = multi_prepare(root)) != RT_OK) return st;
-    if (root->stage_cap < total) {
-        RT_HIP(root, hipStreamSynchronize(s0), "waiting for the staging area");
-        if ((st = grow(root, &root->d_stage, &root->stage_cap, total, "allocating the gather staging area")) != RT_OK) return st;
-    }
     for (int i = 0; i < n_ranks; i++) {
         rt_ctx *c = ranks[i].ctx;
         if ((st = multi_prepare(c)) != RT_OK) return set_err(root, st, rt_last_error(c));
-        if (c->bands_cap < L.floats_of(i)) {
-            RT_HIP(c, hipStreamSynchronize(c->multi_stream), "waiting for the band buffer");
-            if ((st = grow(c, &c->d_bands, &c->bands_cap, L.floats_of(i), "allocating the band buffer")) != RT_OK) return set_err(root, st, rt_last_error(c));
-        }
-        if (c->device != root->device) {
-            /* direct xGMI copies instead of staging through the host; "already enabled" is fine */
-            (void)hipSetDevice(c->device); (void)hipDeviceEnablePeerAccess(root->device, 0);
-            (void)hipSetDevice(root->device); (void)hipDeviceEnablePeerAccess(c->device, 0);
-            (void)hipGetLastError();
-        }
+        (void)peer_access(c, root);      /* direct xGMI copies instead of staging through the host when the platform allows */
     }
-    /* the image so far goes out to its owners.  (root->ev_multi is recorded twice in this function: here, on the
-     * caller's stream, as "the ranks may start", and further down on rank 0's stream as "rank 0's bands are in the
-     * staging area"; a hipStreamWaitEvent captures the record that precedes it, and the calls are in that order.) */
-    if (frame_num > 0) {
-        RT_HIP(root, hipSetDevice(root->device), "selecting device");
-        for (int i = 0; i < n_ranks; i++) RT_HIP(root, copy_bands(L, i, d_frame, root->d_stage + off[i], false, s0), "interleaving bands");
-        RT_HIP(root, hipEventRecord(root->ev_multi, s0), "recording the scatter event");
+    RT_HIP(root, hipSetDevice(root->device), "selecting device");
+
+    /* ---- who renders what -------------------------------------------------------------------------- */
+    BandLayout L;
+    L.W = W; L.H = H; L.band_rows = listed ? 8 : band_rows; L.n = n_ranks;
+    std::vector<RankPlan> plan((size_t)n_ranks);
+    MultiState &ms = root->multi;
+    bool collect_after = false;
+    if (listed) {
+        std::vector<uint32_t> key;
+        for (int i = 0; i < 3; i++) { uint32_t u; std::memcpy(&u, &cam->cam_pos[i], 4); key.push_back(u); }
+        for (int i = 0; i < 3; i++) { uint32_t u; std::memcpy(&u, &cam->tl_pixel_pos[i], 4); key.push_back(u); }
+        for (int i = 0; i < 3; i++) { uint32_t u; std::memcpy(&u, &cam->delta_u[i], 4); key.push_back(u); }
+        for (int i = 0; i < 3; i++) { uint32_t u; std::memcpy(&u, &cam->delta_v[i], 4); key.push_back(u); }
+        key.push_back((uint32_t)W); key.push_back((uint32_t)H); key.push_back((uint32_t)n_ranks);
+        for (int i = 0; i < n_ranks; i++) { key.push_back(ranks[i].scene->uid); key.push_back((uint32_t)ranks[i].ctx->device); }
+        std::vector<int32_t> owner((size_t)tiles_x * tiles_y);
+        if (key != ms.key || ms.lists.size() != (size_t)n_ranks) {
+            /* a new view: interleaved ownership; this call's first launches measure what the tiles cost */
+            if ((st = rt_partition_tiles(nullptr, tiles_x, tiles_y, n_ranks, owner.data())) != RT_OK) return set_err(root, st, "cannot partition the image");
+            ms.lists.assign((size_t)n_ranks, std::vector<uint32_t>());
+            ms.costs.assign((size_t)n_ranks, std::vector<uint32_t>());
+            for (size_t g = 0; g < owner.size(); g++) ms.lists[(size_t)owner[g]].push_back((uint32_t)g);
+            ms.key = key;
+            ms.stage = 0;
+        } else if (ms.stage == 1) {
+            /* the previous call measured the tiles: collect every rank's figures (this waits for those launches, which
+             * the caller has normally consumed already), then deal the tiles out again by cost.  All read-backs happen
+             * here, before any rank is launched, so no rank's launch waits on another rank's kernel. */
+            std::vector<uint32_t> cost((size_t)tiles_x * tiles_y, 0u);
+            bool have_all = true;
+            for (int i = 0; i < n_ranks && have_all; i++) {
+                const size_t cnt = ms.lists[(size_t)i].size();
+                if (cnt == 0) continue;
+                std::vector<uint32_t> ids(cnt), cs(cnt);
+                int32_t got = 0;
+                if (rt_tile_costs(ranks[i].ctx, ids.data(), cs.data(), (int32_t)cnt, &got) != RT_OK || (size_t)got != cnt) { have_all = false; break; }
+                for (size_t k = 0; k < cnt && have_all; k++) {
+                    if (ids[k] != ms.lists[(size_t)i][k]) have_all = false;     /* the rank's context has rendered another view since */
+                    else cost[ids[k]] = cs[k];
+                }
+            }
+            RT_HIP(root, hipSetDevice(root->device), "selecting device");
+            if (have_all) {
+                if ((st = rt_partition_tiles(cost.data(), tiles_x, tiles_y, n_ranks, owner.data())) != RT_OK) return set_err(root, st, "cannot partition the image");
+                ms.lists.assign((size_t)n_ranks, std::vector<uint32_t>());
+                ms.costs.assign((size_t)n_ranks, std::vector<uint32_t>());
+                for (size_t g = 0; g < owner.size(); g++) { ms.lists[(size_t)owner[g]].push_back((uint32_t)g); ms.costs[(size_t)owner[g]].push_back(cost[g]); }
+                ms.stage = 2;
+            } else {
+                ms.stage = 0;            /* (a rank's view was replaced in between: measure again) */
+            }
+        }
+        collect_after = ms.stage == 0;
         for (int i = 0; i < n_ranks; i++) {
-            rt_ctx *c = ranks[i].ctx;
-            RT_HIP(c, hipSetDevice(c->device), "selecting device");
-            RT_HIP(c, hipStreamWaitEvent(c->multi_stream, root->ev_multi, 0), "ordering the scatter");
-            RT_HIP(c, copy_between(c->d_bands, c->device, root->d_stage + off[i], root->device, L.floats_of(i) * 4, c->multi_stream), "copying bands to their GPU");
+            RankPlan &p = plan[(size_t)i];
+            std::memset(&p.spec, 0, sizeof p.spec);
+            p.spec.compact = 1;
+            p.spec.tile_list = ms.lists[(size_t)i].data();
+            p.spec.num_tiles = (int32_t)ms.lists[(size_t)i].size();
+            p.spec.tile_cost = (ms.stage == 2 && p.spec.num_tiles > 0) ? ms.costs[(size_t)i].data() : nullptr;
+            /* (an empty vector's data() may be null, which would read as "no list") */
+            static const uint32_t none = 0;
+            if (!p.spec.tile_list) p.spec.tile_list = &none;
+            p.floats = (size_t)p.spec.num_tiles * 192;
+            if ((st = device_tile_list(root, p.spec.tile_list, p.spec.num_tiles, s0, &p.root_list)) != RT_OK) return st;
         }
     } else {
-        /* frame 0 ignores the buffer's content, but the staging area may still be read by an earlier
-         * call's de-interleave on s0: order the ranks' copies into it behind that */
-        RT_HIP(root, hipSetDevice(root->device), "selecting device");
-        RT_HIP(root, hipEventRecord(root->ev_multi, s0), "recording the start event");
         for (int i = 0; i < n_ranks; i++) {
-            rt_ctx *c = ranks[i].ctx;
-            RT_HIP(c, hipSetDevice(c->device), "selecting device");
-            RT_HIP(c, hipStreamWaitEvent(c->multi_stream, root->ev_multi, 0), "ordering the ranks behind the caller's stream");
+            RankPlan &p = plan[(size_t)i];
+            std::memset(&p.spec, 0, sizeof p.spec);
+            p.spec.band_rows = band_rows; p.spec.band_first = i; p.spec.band_stride = n_ranks; p.spec.compact = 1;
+            p.floats = L.floats_of(i);
         }
     }
-    /* every rank renders its bands (asynchronous launches from this one thread) and sends them back */
+
+    /* ---- buffers: every rank's compact image on its GPU, a landing area per rank on the root's ---------- */
+    std::vector<Stage *> stage((size_t)n_ranks, nullptr);
     for (int i = 0; i < n_ranks; i++) {
         rt_ctx *c = ranks[i].ctx;
-        if (L.bands_of(i) == 0) continue;
-        rt_tile_spec t = {band_rows, i, n_ranks, 1};
+        if (c->bands_cap < plan[(size_t)i].floats || !c->d_bands) {
+            RT_HIP(c, hipSetDevice(c->device), "selecting device");
+            RT_HIP(c, hipStreamSynchronize(c->multi_stream), "waiting for the rank's image buffer");
+            if ((st = grow(c, &c->d_bands, &c->bands_cap, plan[(size_t)i].floats, "allocating the rank's image buffer")) != RT_OK) return set_err(root, st, rt_last_error(c));
+        }
+        if ((st = stage_for(root, c, plan[(size_t)i].floats, s0, &stage[(size_t)i])) != RT_OK) return st;
+    }
+
+    /* ---- the image so far goes out to its owners.  (root->ev_multi is recorded twice in this function: here, on the
+     * caller's stream, as "the ranks may start", and further down on rank 0's stream as "rank 0's image is in the
+     * staging area"; a hipStreamWaitEvent captures the record that precedes it, and the calls are in that order.) */
+    RT_HIP(root, hipSetDevice(root->device), "selecting device");
+    if (frame_num > 0) {
+        for (int i = 0; i < n_ranks; i++) {
+            if (plan[(size_t)i].floats == 0) continue;
+            if (listed) RT_HIP(root, rt_launch_tiles_copy(stage[(size_t)i]->d, d_frame, plan[(size_t)i].root_list, plan[(size_t)i].spec.num_tiles, tiles_x, W, H, 0, s0), "interleaving tiles");
+            else RT_HIP(root, copy_bands(L, i, d_frame, stage[(size_t)i]->d, false, s0), "interleaving bands");
+        }
+    }
+    /* (frame 0 ignores the buffers' content, but the staging areas may still be read by an earlier call's
+     * de-interleave: stage_for has ordered s0 behind that, and the ranks start behind s0) */
+    RT_HIP(root, hipEventRecord(root->ev_multi, s0), "recording the start event");
+    for (int i = 0; i < n_ranks; i++) {
+        rt_ctx *c = ranks[i].ctx;
+        RT_HIP(c, hipSetDevice(c->device), "selecting device");
+        RT_HIP(c, hipStreamWaitEvent(c->multi_stream, root->ev_multi, 0), "ordering the ranks behind the caller's stream");
+        if (frame_num > 0)
+            RT_HIP(c, copy_between(c->d_bands, c->device, stage[(size_t)i]->d, root->device, plan[(size_t)i].floats * 4, c->multi_stream), "copying the image so far to its owner");
+    }
+    /* ---- every rank renders its tiles (asynchronous launches from this one thread) and sends them back ---- */
+    for (int i = 0; i < n_ranks; i++) {
+        rt_ctx *c = ranks[i].ctx;
+        if (plan[(size_t)i].floats == 0) continue;
+        RT_HIP(c, hipSetDevice(c->device), "selecting device");
+        const int32_t cap = batch_cap(c, plan[(size_t)i].floats);
         for (int32_t done = 0; done < n_frames;) {
-            const int32_t k = std::min<int32_t>(n_frames - done, RT_MAX_BATCH_FRAMES);
-            st = rt_render_device_batch(c, ranks[i].scene, cam, rs, times_ms + done, k, frame_num + done, &t, c->d_bands, c->multi_stream);
+            const int32_t k = std::min<int32_t>(n_frames - done, cap);
+            st = rt_render_device_batch(c, ranks[i].scene, cam, rs, times_ms + done, k, frame_num + done, &plan[(size_t)i].spec, c->d_bands, c->multi_stream);
             if (st != RT_OK) return set_err(root, st, rt_last_error(c));
             done += k;
         }
-        RT_HIP(c, copy_between(root->d_stage + off[i], root->device, c->d_bands, c->device, L.floats_of(i) * 4, c->multi_stream), "copying bands to the root GPU");
+        RT_HIP(c, copy_between(stage[(size_t)i]->d, root->device, c->d_bands, c->device, plan[(size_t)i].floats * 4, c->multi_stream), "copying the rank's image to the root GPU");
         RT_HIP(c, hipEventRecord(c->ev_multi, c->multi_stream), "recording the gather event");
     }
     RT_HIP(root, hipSetDevice(root->device), "selecting device");
     for (int i = 0; i < n_ranks; i++) {
-        if (L.bands_of(i) == 0) continue;
+        if (plan[(size_t)i].floats == 0) continue;
         RT_HIP(root, hipStreamWaitEvent(s0, ranks[i].ctx->ev_multi, 0), "ordering the de-interleave behind the copies");
-        RT_HIP(root, copy_bands(L, i, d_frame, root->d_stage + off[i], true, s0), "de-interleaving bands");
+        if (listed) RT_HIP(root, rt_launch_tiles_copy(stage[(size_t)i]->d, d_frame, plan[(size_t)i].root_list, plan[(size_t)i].spec.num_tiles, tiles_x, W, H, 1, s0), "de-interleaving tiles");
+        else RT_HIP(root, copy_bands(L, i, d_frame, stage[(size_t)i]->d, true, s0), "de-interleaving bands");
+        RT_HIP(root, hipEventRecord(stage[(size_t)i]->ev_free, s0), "recording the staging event");
+        stage[(size_t)i]->used = true;
     }
+    if (listed && collect_after) ms.stage = 1;
     return RT_OK;
 }
 
@@ -961,18 +1291,12 @@ extern "C" rt_status rt_render_multi(const rt_rank *ranks, int32_t n_ranks, cons
     if (cam->width <= 0 || cam->height <= 0) return set_err(ctx, RT_ERR_INVALID, "bad image size");
     RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
     const size_t bytes = (size_t)cam->width * (size_t)cam->height * 3 * sizeof(float);
-    if (bytes != ctx->frame_bytes) {
-        if (ctx->d_prev) (void)hipFree(ctx->d_prev);
-        if (ctx->d_out) (void)hipFree(ctx->d_out);
-        ctx->d_prev = ctx->d_out = nullptr;
-        ctx->frame_bytes = 0;
-        RT_HIP(ctx, hipMalloc((void **)&ctx->d_prev, bytes), "allocating previous-frame buffer");
-        RT_HIP(ctx, hipMalloc((void **)&ctx->d_out, bytes), "allocating frame buffer");
-        ctx->frame_bytes = bytes;
-    }
-    RT_HIP(ctx, hipMemcpy(ctx->d_out, previous_render, bytes, hipMemcpyHostToDevice), "copying previous frame");
-    rt_status st = rt_render_multi_device(ranks, n_ranks, cam, rs, times_ms, n_frames, *frame_num, 8, ctx->d_out, nullptr);
+    rt_status st = ensure_frame_buffers(ctx, bytes);
     if (st != RT_OK) return st;
+    RT_HIP(ctx, hipMemcpy(ctx->d_out, previous_render, bytes, hipMemcpyHostToDevice), "copying previous frame");
+    st = rt_render_multi_device(ranks, n_ranks, cam, rs, times_ms, n_frames, *frame_num, 0, ctx->d_out, nullptr);
+    if (st != RT_OK) return st;
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
     RT_HIP(ctx, hipStreamSynchronize(nullptr), "render kernels");
     for (int i = 0; i < n_ranks; i++)
         if ((st = rt_ctx_synchronize(ranks[i].ctx)) != RT_OK) return set_err(ctx, st, rt_last_error(ranks[i].ctx));

@@ -43,6 +43,18 @@
 #define RT_DEF_MIX_BREAK 40          /*     this many together */
 #define RT_DEF_DESCEND_KEEP 24       /* the descend loop ends once fewer than this many 64ths of its lanes remain */
 #define RT_DEF_SHADE_BATCH 40        /* scenes without a mesh: hits are shaded once this many lanes hold one */
+/* What a pixel is charged for (the tile costs a view's first launch collects: longest-job-first schedule, cost-balanced
+ * tile ownership over GPUs): per traversal macro step, per generated bounce ray, per shaded hit.  Fitted to the kernel
+ * times of 1/2/4/8-rank shares of the monkey run (tools/fit_cost_weights.py, profiles/r03/cost_weights.txt). */
+#ifndef RT_COST_STEP
+#define RT_COST_STEP 4
+#endif
+#ifndef RT_COST_GEN
+#define RT_COST_GEN 3
+#endif
+#ifndef RT_COST_HIT
+#define RT_COST_HIT 8
+#endif
 #define RT_JOB_FRAME_SHIFT 22          /* a job = tile | frame << 22 (2^28 pixels are 2^22 tiles) */
 #define RT_JOB_TILE_MASK 0x003fffffu
 #define RT_INF_F 1073741824.0f       /* reference `1 << 31 - 1` == 1 << 30, src/objects.cu:6 */
@@ -119,6 +131,8 @@ typedef struct {
     int32_t band_rows, band_first, band_stride, compact;
     int32_t tiles_x;               /* 8x8 tiles per row of tiles */
     int32_t num_tiles;             /* tiles this launch renders */
+    const uint32_t *tile_list;     /* or NULL (bands): local tile t is the image's tile tile_list[t] = ty * tiles_x + tx; with `compact`
+                                      the output holds the listed tiles back to back, 64 pixels each, row-major inside a tile */
     uint32_t tile_stride;          /* ticket t renders tile (t * tile_stride) % num_tiles; coprime to num_tiles */
     const uint32_t *tile_order;    /* or, if not NULL, tile tile_order[t] (expensive-looking tiles first) */
     int32_t num_heavy_tiles;       /* multi-frame launches: this many leading entries of tile_order go first for ALL frames */
@@ -138,10 +152,6 @@ typedef struct {
     int32_t hit_break;             /* ... or this many hold a hit to shade */
     int32_t hit_low, mix_break;    /* ... or at least hit_low hold a hit and hits + cheap-work lanes together reach mix_break */
     int32_t shade_batch;           /* scenes without a mesh: hits are shaded once this many lanes hold one */
-    /* pooled kernel */
-    int32_t pool_fill;             /* a box-test executor hands on / takes on rays once this many of its lanes are not stepping */
-    int32_t pool_low;              /* ... or at once, when fewer than this many are */
-    int32_t pool_leaf_batch;       /* triangle tests wait for this many posted rays (or more than box tests have) */
     const float *tri_uv;           /* 6 floats per triangle, or NULL */
     const float *tex_data;         /* IMAGE texture texels (rgb floats), or NULL */
     /* frame buffers */

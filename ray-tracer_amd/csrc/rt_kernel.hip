@@ -35,8 +35,7 @@
  *    rt_blend_kernel (below) folds the planes into the frame buffer in frame order.
  *
  * The per-pixel sections (shade / fetch / generate, the primitive tests) are in rt_pixel.h; this
- * file has the two kernels built from them - rt_render_kernel (the default) and the opt-in
- * rt_render_pool_kernel - and the launchers.
+ * file has the render kernel built from them, the small streaming kernels and the launchers.
  *
  * No MFMA: there is no dense contraction anywhere in this workload.
  * Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize (the reference's a*b+c
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : RT_SMALL_WG_WAVES) void rt_ren
                 RT_LAP(TM_CTL);
                 if (p.mode == M_WAIT) {
                     RT_STAT(ST_WORK_ITER);
-                    p.frame_steps += (unsigned)RT_MAX_BATCH_FRAMES;   /* one more traversal macro step (the bits above the frame index) */
+                    p.frame_steps += (unsigned)(RT_COST_STEP * RT_MAX_BATCH_FRAMES);   /* one more traversal macro step (the bits above the frame index) */
                     /* one macro step: descend to a leaf (or run out of children), test the
                      * leaf's triangles, pop the next deferred sibling.  The lane's whole
                      * traversal state is `cur` (+ the stack): an internal node to descend from,
@@ -310,392 +309,6 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : RT_SMALL_WG_WAVES) void rt_ren
     RT_STATS_FLUSH();
 }
 
-/* =============================================================================================
- * The pooled kernel (mesh scenes): pixels stay with their lanes, RAYS do not.
- *
- * Measured on the kernel above (tools/costmap.py, tools/wave_probe.py): a wave that owns 64
- * expensive pixels executes ~4x the traversal steps any one of its lanes needs (at every step
- * only the lanes in the same phase - box tests or triangle tests - take part: ~19 and ~10 of 64),
- * and a frame is as long as its slowest wave.  Here a lane that needs a mesh traversal writes
- * its ray to a record in LDS (slot = thread id) and posts the slot on a queue; ANY wave of the
- * workgroup that has nothing better to do takes up to 64 posted rays of ONE phase and steps them:
- *
- *   node queue -> box-test executor: descends / pops until a ray reaches a leaf (posted on the
- *                 leaf queue) or runs out of stack (finished: the owner lane is told);
- *   leaf queue -> triangle-test executor: tests the leaf's triangles, posts the ray back.
- *
- * So box tests run with (nearly) full waves of rays that all need a box test, likewise triangle
- * tests, the 16 waves of a workgroup share the rays of its most expensive pixels, and waves whose
- * own pixels are finished keep executing for the others until the workgroup is done.
- *
- * The traversal is still the reference's (src/objects.cu:487-532): same visit order, same push
- * order, same comparisons.  Two representation changes make a ray small enough to park
- * (48 bytes + 2 bytes per stack level): the stack holds only the index of the node whose second
- * child was deferred, and a pop re-derives that child's entry distance by running the parent's
- * two box tests again - the same operations on the same operands, hence the same bits (and the
- * same test the reference itself repeats when it pops, :499-501).
- *
- * Queue protocol (LDS, workgroup scope): head / tail counters are monotonic; a producer reserves
- * positions with one atomic add on tail, waits for each position to be EMPTY, then stores the
- * slot id with release semantics; a consumer reserves [head, head + n) with a compare-and-swap
- * bounded by tail, waits for each position to be filled, takes the id and stores EMPTY.  Nobody
- * waits on anything but another wave's few-instruction critical section.
- * ============================================================================================= */
-#define RT_POOL_DONE 0xffffffffu        /* record.cur once the traversal is finished */
-#define RT_POOL_EMPTY 0xffffffffu       /* a free queue position */
-#define RT_POOL_QCAP 1024u              /* queue capacity (power of two, >= threads per workgroup) */
-#define RT_META_POP 0x80000000u         /* record.meta: the ray must pop before it goes on */
-#define RT_META_SP_SHIFT 24             /* ... bits 28..24 stack pointer, bits 23..0 best triangle + 1 */
-#define RT_META_PRIM_MASK 0x00ffffffu
-#define RT_POOL_SPIN_LIMIT (1 << 24)
-enum { E_FREE = 0, E_NODE = 1, E_POP = 2, E_PARK_LEAF = 3, E_PARK_DONE = 4 };
-/* control words */
-enum { C_NODE_HEAD = 0, C_NODE_TAIL = 1, C_LEAF_HEAD = 2, C_LEAF_TAIL = 3, C_LIVE = 4, C_ABORT = 5, C_WORDS = 16 };
-
-#define RT_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define RT_ST(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define RT_ST_REL(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP)
-#define RT_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
-
-__device__ __forceinline__ int rt_rank(unsigned long long m)
-{
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-}
-
-/* posts `slot` for every lane with doit set (one reservation per wave) */
-__device__ __forceinline__ void pool_push(uint32_t *tail, uint32_t *items, bool doit, uint32_t slot, uint32_t *abort_flag)
-{
-    if (doit) {
-        const unsigned long long m = __ballot(1);
-        const int rank = rt_rank(m);
-        uint32_t base = 0;
-        if (rank == 0) base = __hip_atomic_fetch_add(tail, (uint32_t)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        uint32_t *it = items + ((base + (uint32_t)rank) & (RT_POOL_QCAP - 1u));
-        int spin = 0;
-        while (RT_LD(it) != RT_POOL_EMPTY) {
-            if (++spin > RT_POOL_SPIN_LIMIT) { RT_ST(abort_flag, 1u); break; }
-        }
-        RT_ST_REL(it, slot);
-    }
-}
-
-/* the whole wave calls; lanes with `want` set receive a posted slot id, or -1 */
-__device__ __forceinline__ int pool_grab(uint32_t *head_tail, uint32_t *items, bool want, int lane, uint32_t *abort_flag)
-{
-    const unsigned long long m = __ballot(want);
-    const int n_want = __popcll(m);
-    if (n_want == 0) return -1;
-    uint32_t h = 0;
-    int n = 0;
-    if (lane == 0) {
-        for (;;) {
-            h = RT_LD(head_tail);
-            const uint32_t t = RT_LD(head_tail + 1);
-            const int avail = (int)(t - h);
-            n = avail < n_want ? avail : n_want;
-            if (n <= 0) { n = 0; break; }
-            uint32_t expected = h;
-            if (__hip_atomic_compare_exchange_strong(head_tail, &expected, h + (uint32_t)n, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-        }
-    }
-    h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
-    n = __builtin_amdgcn_readfirstlane(n);
-    int slot = -1;
-    const int rank = rt_rank(m);
-    if (want && rank < n) {
-        uint32_t *it = items + ((h + (uint32_t)rank) & (RT_POOL_QCAP - 1u));
-        uint32_t v;
-        int spin = 0;
-        while ((v = RT_LD(it)) == RT_POOL_EMPTY) {
-            if (++spin > RT_POOL_SPIN_LIMIT) { RT_ST(abort_flag, 1u); v = 0u; break; }
-        }
-        RT_ST(it, RT_POOL_EMPTY);
-        slot = (int)v;
-    }
-    RT_ACQUIRE();
-    return slot;
-}
-
-template <int NT, bool SCENE_LDS>
-__global__ __launch_bounds__(NT) void rt_render_pool_kernel(const rt_kernel_args a)
-{
-    extern __shared__ v4f lds_raw[];
-    const int tid = threadIdx.x;
-    const int lane = tid & (RT_WAVE - 1);
-
-    Lds L;
-    v4f *dyn;
-    if (SCENE_LDS) {
-        for (int i = tid; i < a.blob_f4; i += NT) lds_raw[i] = ((const v4f *)a.blob)[i];
-        L.nodes = lds_raw + a.off_nodes;
-        L.tris = lds_raw + a.off_tris;
-        L.objs = lds_raw + a.off_objlds;
-        L.meshes = lds_raw + a.off_meshes;
-        L.objtab = lds_raw + a.off_objtab;
-        dyn = lds_raw + a.blob_f4;
-    } else {
-        const v4f *g = (const v4f *)a.blob;
-        L.nodes = g + a.off_nodes;
-        L.tris = g + a.off_tris;
-        L.objs = g + a.off_objlds;
-        L.meshes = g + a.off_meshes;
-        L.objtab = g + a.off_objtab;
-        dyn = lds_raw;
-    }
-    /* ray records, one per thread: q0 = (origin, best distance) q1 = (direction, current reference)
-     * q2 = (1/direction, meta) */
-    v4f *rq0 = dyn, *rq1 = dyn + NT, *rq2 = dyn + 2 * NT;
-    uint32_t *node_q = (uint32_t *)(dyn + 3 * NT);
-    uint32_t *leaf_q = node_q + RT_POOL_QCAP;
-    uint32_t *ctl = leaf_q + RT_POOL_QCAP;
-    uint16_t *stack = (uint16_t *)(ctl + C_WORDS);       /* [stack_entries + 1][NT] parent node of the deferred child */
-    for (int i = tid; i < (int)RT_POOL_QCAP; i += NT) { node_q[i] = RT_POOL_EMPTY; leaf_q[i] = RT_POOL_EMPTY; }
-    if (tid < C_WORDS) ctl[tid] = tid == C_LIVE ? (uint32_t)(NT / RT_WAVE) : 0u;
-    __syncthreads();
-#define REC_BEST(slot) (((float *)(rq0 + (slot))) + 3)
-#define REC_CUR(slot) (((uint32_t *)(rq1 + (slot))) + 3)
-#define REC_META(slot) (((uint32_t *)(rq2 + (slot))) + 3)
-
-    Frame f;
-    frame_init(f, a);
-    Px p;
-    px_init(p);
-    int w_obj = -1;             /* object index of the mesh this lane's ray is in */
-    bool retired = false;       /* wave-uniform: every pixel of this wave is finished */
-    Chunk ch;
-    ch.next = 0; ch.end = 0; ch.frame = 0; ch.exhausted = false;
-#ifdef RT_STATS
-    unsigned st_exec[ST_N], st_lanes[ST_N];
-    for (int i = 0; i < ST_N; i++) { st_exec[i] = 0; st_lanes[i] = 0; }
-    unsigned long long st_time[TM_N], st_last = __builtin_readcyclecounter();
-    const unsigned long long st_wall0 = wall_clock64();
-    for (int i = 0; i < TM_N; i++) st_time[i] = 0;
-#endif
-    unsigned long long idle_since = 0;
-
-    for (;;) {
-        RT_STAT(ST_ITER);
-        /* ---- traversals of my lanes that have finished: merge (smaller distance, or equal and
-         * later in the object list, src/raytracer.cu:36) */
-        if (p.mode == M_WAIT && RT_LD(REC_CUR(tid)) == RT_POOL_DONE) {
-            RT_ACQUIRE();
-            const float w_best = *REC_BEST(tid);
-            const int w_prim = (int)(*REC_META(tid) & RT_META_PRIM_MASK) - 1;
-            if (w_prim >= 0 && (w_best < p.best_t || (w_best == p.best_t && w_obj > p.best_obj))) {
-                p.best_t = w_best; p.best_obj = w_obj; p.best_prim = w_prim;
-            }
-            p.mode = p.next_mesh >= a.num_meshes ? M_SHADE : M_MESH;
-        }
-        const int n_live = __popcll(__ballot(p.mode != M_DONE));
-        int n_ready = __popcll(__ballot(p.mode == M_SHADE || p.mode == M_MESH || p.mode == M_GEN || p.mode == M_FETCH));
-        const int half_live = (n_live + 1) >> 1;
-        const int thr = a.ready_break < half_live ? a.ready_break : (half_live > 0 ? half_live : 1);
-        int n_node = __builtin_amdgcn_readfirstlane((int)(RT_LD(ctl + C_NODE_TAIL) - RT_LD(ctl + C_NODE_HEAD)));
-        int n_leaf = __builtin_amdgcn_readfirstlane((int)(RT_LD(ctl + C_LEAF_TAIL) - RT_LD(ctl + C_LEAF_HEAD)));
-        RT_LAP(TM_CTL);
-
-        /* ---- the pixels' own work, once enough lanes want it (or there is nothing else to do) */
-        if (n_ready >= thr || (n_ready > 0 && n_node + n_leaf <= 0)) {
-            idle_since = 0;
-            if (p.mode == M_SHADE && p.best_obj < 0) px_shade_miss(p, a, f);
-            if (p.mode == M_SHADE) {
-                RT_STAT(ST_SHADE);
-                px_shade(p, a, f, L);
-            }
-            RT_LAP(TM_SHADE);
-            px_fetch(p, ch, a, f, lane);
-            RT_LAP(TM_FETCH);
-            if (p.mode == M_GEN) {
-                RT_STAT(ST_GEN);
-                px_gen<true>(p, a, L);
-            }
-            RT_LAP(TM_GEN);
-            /* MESH: the next mesh whose root box the ray enters; its traversal is posted */
-            bool submit = false;
-            uint32_t sub_root = 0;
-            while (p.mode == M_MESH) {
-                RT_STAT(ST_MESH);
-                if (p.next_mesh >= a.num_meshes) { p.mode = M_SHADE; break; }
-                const v4f m0 = L.meshes[2 * p.next_mesh], m1 = L.meshes[2 * p.next_mesh + 1];
-                p.next_mesh++;
-                /* a NaN direction (Box-Muller on a zero draw) fails every
-                 * triangle test: the mesh cannot be hit, no need to walk it */
-                if (p.d.x != p.d.x || p.d.y != p.d.y || p.d.z != p.d.z) continue;
-                /* the root is pushed unconditionally and tested when popped (src/objects.cu:494-501) */
-                const uint32_t root_ref = __float_as_uint(m1.z);
-                float rd;
-                const bool rh = box_test(m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, p.o, p.inv, rd);
-                if (!rh || rd > RT_INF_F || ((root_ref & RT_REF_CHAIN) && !(rd < RT_INF_F))) continue;
-                w_obj = (int)__float_as_uint(m1.w);
-                submit = true; sub_root = root_ref;
-                p.mode = M_WAIT;
-                RT_STAT(ST_MESH_START);
-            }
-            if (submit) {
-                v4f r0, r1, r2;
-                r0.x = p.o.x; r0.y = p.o.y; r0.z = p.o.z; r0.w = RT_INF_F;
-                r1.x = p.d.x; r1.y = p.d.y; r1.z = p.d.z; r1.w = __uint_as_float(sub_root);
-                r2.x = p.inv.x; r2.y = p.inv.y; r2.z = p.inv.z; r2.w = __uint_as_float(0u);
-                rq0[tid] = r0; rq1[tid] = r1; rq2[tid] = r2;
-            }
-            pool_push(ctl + C_NODE_TAIL, node_q, submit && !(sub_root & RT_REF_LEAF), (uint32_t)tid, ctl + C_ABORT);
-            pool_push(ctl + C_LEAF_TAIL, leaf_q, submit && (sub_root & RT_REF_LEAF), (uint32_t)tid, ctl + C_ABORT);
-            RT_LAP(TM_MESH);
-            n_node = __builtin_amdgcn_readfirstlane((int)(RT_LD(ctl + C_NODE_TAIL) - RT_LD(ctl + C_NODE_HEAD)));
-            n_leaf = __builtin_amdgcn_readfirstlane((int)(RT_LD(ctl + C_LEAF_TAIL) - RT_LD(ctl + C_LEAF_HEAD)));
-        }
-
-        if (n_leaf > 0 && (n_leaf >= n_node || n_leaf >= a.pool_leaf_batch)) {
-            /* ================= triangle-test executor: one batch ============================ */
-            idle_since = 0;
-            const int e_slot = pool_grab(ctl + C_LEAF_HEAD, leaf_q, true, lane, ctl + C_ABORT);
-            if (e_slot >= 0) {
-                const v4f r0 = rq0[e_slot], r1 = rq1[e_slot];
-                uint32_t e_meta = *REC_META(e_slot);
-                const V3 e_o = v3(r0.x, r0.y, r0.z), e_d = v3(r1.x, r1.y, r1.z);
-                float e_best = r0.w;
-                const uint32_t e_cur = __float_as_uint(r1.w);
-                /* leaf: strict <, first triangle wins ties (src/objects.cu:596) */
-                const int start = (int)(e_cur & RT_REF_START_MASK);
-                const int count = (int)((e_cur >> RT_REF_COUNT_SHIFT) & RT_REF_COUNT_MAX);
-                uint32_t e_prim1 = e_meta & RT_META_PRIM_MASK;
-                for (int k = 0; k < count; k++) {
-                    RT_STAT(ST_LEAF_TRI);
-                    float t, u, v;
-                    const bool h = tri_test(L.tris, start + k, e_o, e_d, t, u, v);
-                    if (h && t < e_best) { e_best = t; e_prim1 = (uint32_t)(start + k + 1); }
-                }
-                *REC_BEST(e_slot) = e_best;
-                const uint32_t e_sp = (e_meta >> RT_META_SP_SHIFT) & 31u;
-                const bool finished = e_sp == 0u;          /* nothing deferred: the traversal is over */
-                *REC_META(e_slot) = e_prim1 | (e_sp << RT_META_SP_SHIFT) | (finished ? 0u : RT_META_POP);
-                if (finished) RT_ST_REL(REC_CUR(e_slot), RT_POOL_DONE);
-                pool_push(ctl + C_NODE_TAIL, node_q, !finished, (uint32_t)e_slot, ctl + C_ABORT);
-            }
-            RT_LAP(TM_LEAF);
-        } else if (n_node > 0) {
-            /* ================= box-test executor =========================================== */
-            idle_since = 0;
-            int e_state = E_FREE, e_slot = 0, e_sp = 0;
-            V3 e_o = v3(0.f, 0.f, 0.f), e_inv = e_o;
-            float e_best = RT_INF_F;
-            uint32_t e_cur = 0, e_prim1 = 0;
-            for (;;) {
-                const int n_act = __popcll(__ballot(e_state == E_NODE || e_state == E_POP));
-                const int n_park = __popcll(__ballot(e_state >= E_PARK_LEAF));
-                if (n_act == 0 || RT_WAVE - n_act >= a.pool_fill || (n_park > 0 && n_act < a.pool_low)) {
-                    /* ---- hand on the rays that left the box-test phase ... */
-                    if (e_state == E_PARK_LEAF) {
-                        *REC_CUR(e_slot) = e_cur;
-                        *REC_META(e_slot) = e_prim1 | ((uint32_t)e_sp << RT_META_SP_SHIFT);
-                    }
-                    pool_push(ctl + C_LEAF_TAIL, leaf_q, e_state == E_PARK_LEAF, (uint32_t)e_slot, ctl + C_ABORT);
-                    if (e_state == E_PARK_DONE) RT_ST_REL(REC_CUR(e_slot), RT_POOL_DONE);
-                    if (e_state >= E_PARK_LEAF) e_state = E_FREE;
-                    /* ---- ... see whether my own pixels want me back ... */
-                    const bool mine = p.mode == M_WAIT && RT_LD(REC_CUR(tid)) == RT_POOL_DONE;
-                    const int n_mine = __popcll(__ballot(mine)) + n_ready;
-                    const bool preempt = n_mine >= thr;
-                    /* ---- ... and take on waiting rays */
-                    if (!preempt) {
-                        const int s = pool_grab(ctl + C_NODE_HEAD, node_q, e_state == E_FREE, lane, ctl + C_ABORT);
-                        if (s >= 0) {
-                            const v4f r0 = rq0[s], r2 = rq2[s];
-                            e_slot = s;
-                            e_o = v3(r0.x, r0.y, r0.z); e_best = r0.w;
-                            e_inv = v3(r2.x, r2.y, r2.z);
-                            const uint32_t meta = __float_as_uint(r2.w);
-                            e_cur = *REC_CUR(s);
-                            e_prim1 = meta & RT_META_PRIM_MASK;
-                            e_sp = (int)((meta >> RT_META_SP_SHIFT) & 31u);
-                            e_state = (meta & RT_META_POP) ? E_POP : E_NODE;
-                        }
-                    }
-                    const bool held = e_state == E_NODE || e_state == E_POP;
-                    if (preempt || __ballot(held) == 0ull) {
-                        /* leave: whatever is still in flight goes back on the queue */
-                        if (held) {
-                            *REC_CUR(e_slot) = e_cur;
-                            *REC_META(e_slot) = e_prim1 | ((uint32_t)e_sp << RT_META_SP_SHIFT) | (e_state == E_POP ? RT_META_POP : 0u);
-                        }
-                        pool_push(ctl + C_NODE_TAIL, node_q, held, (uint32_t)e_slot, ctl + C_ABORT);
-                        break;
-                    }
-                }
-                if (e_state == E_NODE || e_state == E_POP) {
-                    const bool popping = e_state == E_POP;
-                    if (popping && e_sp == 0) {
-                        e_state = E_PARK_DONE;          /* nothing deferred: the traversal is over */
-                    } else {
-                        RT_STAT(ST_NODE);
-                        /* a pop re-runs the two box tests of the node whose second child was deferred */
-                        uint32_t idx = e_cur & RT_REF_NODE_MASK;
-                        if (popping) { e_sp--; idx = (uint32_t)stack[e_sp * NT + e_slot]; }
-                        const v4f *n = L.nodes + 4 * (int)idx;
-                        const v4f q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-                        float ld, rdist;
-                        const bool lh = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, e_o, e_inv, ld);
-                        const bool rh2 = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, e_o, e_inv, rdist);
-                        const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
-                        const bool l_first = ld < rdist;
-                        /* Of two entered children the one pushed first (left when l_first) is
-                         * visited second: it is the deferred sibling (src/objects.cu:503-531). */
-                        const uint32_t deferred_ref = l_first ? lref : rref;
-                        const float deferred_d = l_first ? ld : rdist;
-                        if (popping) {
-                            /* an entry is taken iff !(dist > best) (:501); through a collapsed
-                             * chain iff dist < best (:517) */
-                            const bool take = (deferred_ref & RT_REF_CHAIN) ? (deferred_d < e_best) : !(deferred_d > e_best);
-                            if (take) {
-                                e_cur = deferred_ref;
-                                e_state = (deferred_ref & RT_REF_LEAF) ? E_PARK_LEAF : E_NODE;
-                            }
-                        } else {
-                            const bool l_push = lh && ld < e_best;
-                            const bool r_push = rh2 && rdist < e_best;
-                            const bool both = l_push && r_push;
-                            const bool entered = l_push || r_push;
-                            stack[e_sp * NT + e_slot] = (uint16_t)idx;
-                            e_sp += both ? 1 : 0;
-                            const uint32_t next = both ? (l_first ? rref : lref) : (l_push ? lref : rref);
-                            if (entered) {
-                                e_cur = next;
-                                if (next & RT_REF_LEAF) e_state = E_PARK_LEAF;
-                            } else {
-                                e_state = E_POP;
-                            }
-                        }
-                    }
-                }
-            }
-            RT_LAP(TM_DESCEND);
-        } else {
-            /* ---- nothing to execute */
-            if (!retired && __ballot(p.mode != M_DONE) == 0ull) {
-                retired = true;
-                if (lane == 0) __hip_atomic_fetch_sub(ctl + C_LIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            const uint32_t live = (uint32_t)__builtin_amdgcn_readfirstlane((int)RT_LD(ctl + C_LIVE));
-            const uint32_t aborted = (uint32_t)__builtin_amdgcn_readfirstlane((int)RT_LD(ctl + C_ABORT));
-            if ((retired && live == 0u) || aborted) break;
-            if (n_ready == 0) {
-                /* watchdog: no wave of a healthy workgroup idles this long (100 MHz ticks) */
-                const unsigned long long now = wall_clock64();
-                if (idle_since == 0) idle_since = now;
-                if (now - idle_since > 3000000000ull) { RT_ST(ctl + C_ABORT, 1u); }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            RT_LAP(TM_POP);
-        }
-    }
-    if (lane == 0 && RT_LD(ctl + C_ABORT)) atomicAdd(a.tile_counter + 1, 1u);
-    RT_STATS_FLUSH();
-#undef REC_BEST
-#undef REC_CUR
-#undef REC_META
-}
-
 /* The sequential part of a multi-frame launch (src/raytracer.cu:109-112, once per frame): the image
  * after frame n is (c_n + image * n) / (n + 1), c_n = that frame's per-pixel mean (plane n - frame_num
  * of `partial`).  In place on `frame`; its content is used only when frame_num > 0. */
@@ -716,6 +329,67 @@ extern "C" hipError_t rt_launch_blend(const float *partial, long long plane_floa
 {
     const long long blocks = (n_floats + 255) / 256;
     hipLaunchKernelGGL(rt_blend_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, partial, plane_floats, num_frames, frame_num, frame, n_floats);
+    return hipGetLastError();
+}
+
+/* float i of a tile list's compact image (tile k = i / 192, 64 pixels of 3 floats, row-major inside the tile) -> its
+ * index in the full W x H frame, or -1 for the part of a ragged edge tile that lies outside the image */
+__device__ __forceinline__ long long rt_tile_float_index(long long i, const uint32_t *tile_list, int tiles_x, int W, int H)
+{
+    const long long k = i / 192;
+    const int r = (int)(i - k * 192), within = r / 3, c = r - within * 3;
+    const int g = (int)tile_list[k];
+    const int ty = g / tiles_x, tx = g - ty * tiles_x;
+    const int x = tx * 8 + (within & 7), y = ty * 8 + (within >> 3);
+    if (x >= W || y >= H) return -1;
+    return ((long long)y * W + x) * 3 + c;
+}
+
+/* the same fold for a launch that rendered a LIST of tiles into a full-layout frame: only the listed tiles' pixels are
+ * touched (planes and frame are both full W x H frames) */
+__global__ void rt_blend_tiles_kernel(const float *partial, long long plane_floats, int num_frames, int frame_num, float *frame,
+                                      const uint32_t *tile_list, long long n_floats, int tiles_x, int W, int H)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_floats) return;
+    const long long j = rt_tile_float_index(i, tile_list, tiles_x, W, H);
+    if (j < 0) return;
+    float r = frame_num > 0 ? frame[j] : 0.0f;
+    for (int k = 0; k < num_frames; k++) {
+        const int n = frame_num + k;
+        const float previous_sum = r * (float)n;
+        r = (partial[(long long)k * plane_floats + j] + previous_sum) / (float)(n + 1);
+    }
+    frame[j] = rt_canon_nan(r);
+}
+
+extern "C" hipError_t rt_launch_blend_tiles(const float *partial, long long plane_floats, int num_frames, int frame_num, float *frame,
+                                            const uint32_t *tile_list, int n_tiles, int tiles_x, int W, int H, hipStream_t stream)
+{
+    const long long n_floats = (long long)n_tiles * 192;
+    hipLaunchKernelGGL(rt_blend_tiles_kernel, dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, stream, partial, plane_floats, num_frames, frame_num,
+                       frame, tile_list, n_floats, tiles_x, W, H);
+    return hipGetLastError();
+}
+
+/* The exchange step of the tile-list partition: a rank's compact image (its tiles back to back)
+ * <-> the full frame.  to_frame: frame[tile pixels] = compact; otherwise compact = frame[tile pixels].  Streaming:
+ * 12 B read + 12 B written per pixel; the compact side is contiguous, the frame side comes in 96-byte runs. */
+__global__ void rt_tiles_copy_kernel(float *compact, float *frame, const uint32_t *tile_list, long long n_floats, int tiles_x, int W, int H, int to_frame)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_floats) return;
+    const long long j = rt_tile_float_index(i, tile_list, tiles_x, W, H);
+    if (j < 0) return;
+    if (to_frame) frame[j] = compact[i];
+    else compact[i] = frame[j];
+}
+
+extern "C" hipError_t rt_launch_tiles_copy(float *compact, float *frame, const uint32_t *tile_list, int n_tiles, int tiles_x, int W, int H, int to_frame, hipStream_t stream)
+{
+    const long long n_floats = (long long)n_tiles * 192;
+    if (n_floats == 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_tiles_copy_kernel, dim3((unsigned)((n_floats + 255) / 256)), dim3(256), 0, stream, compact, frame, tile_list, n_floats, tiles_x, W, H, to_frame);
     return hipGetLastError();
 }
 
@@ -798,31 +472,6 @@ static void rt_launch_one(const rt_kernel_args *args, int blocks, size_t lds_byt
 {
     (void)hipFuncSetAttribute((const void *)rt_render_kernel<NT, HAS_MESH, SCENE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL((rt_render_kernel<NT, HAS_MESH, SCENE_LDS>), dim3(blocks), dim3(NT), lds_bytes, stream, *args);
-}
-
-template <int NT, bool SCENE_LDS>
-static void rt_launch_pool(const rt_kernel_args *args, int blocks, size_t lds_bytes, hipStream_t stream)
-{
-    (void)hipFuncSetAttribute((const void *)rt_render_pool_kernel<NT, SCENE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((rt_render_pool_kernel<NT, SCENE_LDS>), dim3(blocks), dim3(NT), lds_bytes, stream, *args);
-}
-
-/* mesh scenes, pooled traversal */
-extern "C" hipError_t rt_launch_render_pool(const rt_kernel_args *args, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream)
-{
-    if (!scene_in_lds) {
-        if (threads != 1024) return hipErrorInvalidValue;
-        rt_launch_pool<1024, false>(args, blocks, lds_bytes, stream);
-        return hipGetLastError();
-    }
-    switch (threads) {
-        case 256: rt_launch_pool<256, true>(args, blocks, lds_bytes, stream); break;
-        case 512: rt_launch_pool<512, true>(args, blocks, lds_bytes, stream); break;
-        case 768: rt_launch_pool<768, true>(args, blocks, lds_bytes, stream); break;
-        case 1024: rt_launch_pool<1024, true>(args, blocks, lds_bytes, stream); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
 }
 
 extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream)

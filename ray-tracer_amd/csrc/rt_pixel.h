@@ -135,7 +135,7 @@ struct Px {
     uint32_t rng;
     V3 colour, fin, thr, o, d, inv, primary;
     int sample, bounce;
-    unsigned pxy;                /* the pixel: y << 16 | x (images are at most 32,768 pixels on a side) */
+    unsigned id;                 /* the pixel: 64 * (tile of this launch) + (row in tile * 8 + column in tile) */
     float cur_n;                 /* Ray::current_refractive_index src/ray.cu:56,144 */
     float best_t;
     int best_obj, best_prim, next_mesh;
@@ -172,7 +172,7 @@ __device__ __forceinline__ void px_init(Px &p)
     const V3 z = v3(0.f, 0.f, 0.f);
     p.mode = M_FETCH; p.rng = 0;
     p.colour = z; p.fin = z; p.thr = z; p.o = z; p.d = z; p.inv = z; p.primary = z;
-    p.sample = 0; p.bounce = 0; p.pxy = 0;
+    p.sample = 0; p.bounce = 0; p.id = 0;
     p.cur_n = 1.0f; p.best_t = RT_INF_F;
     p.best_obj = -1; p.best_prim = -1; p.next_mesh = 0; p.frame_steps = 0;
     RT_COST(p.c_steps = 0; p.c_t0 = 0; p.c_wsteps = 0);
@@ -190,6 +190,24 @@ __device__ __forceinline__ void frame_init(Frame &f, const rt_kernel_args &a)
     f.tiles_per_band = a.tiles_x * (a.band_rows >> 3);
 }
 
+/* tile t of this launch -> its place in the image (tx, ty in tiles) and, for the compact band layout, the row of
+ * the output buffer its first pixel row goes to */
+__device__ __forceinline__ void tile_place(const rt_kernel_args &a, const Frame &f, int t, int &tx, int &ty, int &compact_row)
+{
+    if (a.tile_list) {
+        const int g = (int)a.tile_list[t];
+        ty = g / a.tiles_x; tx = g - ty * a.tiles_x;
+        compact_row = 0;
+    } else {
+        const int band_local = t / f.tiles_per_band;
+        const int in_band = t - band_local * f.tiles_per_band;
+        const int tyb = in_band / a.tiles_x;
+        tx = in_band - tyb * a.tiles_x;
+        ty = (a.band_first + band_local * a.band_stride) * (a.band_rows >> 3) + tyb;
+        compact_row = band_local * a.band_rows + tyb * 8;
+    }
+}
+
 /* A pixel's samples are done: blend with the previous frame and store (src/raytracer.cu:107-112,
  * :133-135).
  *
@@ -199,27 +217,23 @@ __device__ __forceinline__ void frame_init(Frame &f, const rt_kernel_args &a)
  * sequential is the blend, (c + prev * n) / (n + 1) with prev = the pixel's value after frame k.
  * So each frame only stores c, the mean of its own samples, into its plane of a scratch buffer
  * (plain stores, no ordering between frames needed), and a small kernel launched behind this one
- * (rt_blend_kernel) folds the planes into the frame buffer in frame order. */
+ * (rt_blend_kernel) folds the planes into the frame buffer in frame order; NaN pixels are made the one
+ * canonical quiet NaN there (any NaN plane value makes the blended value a NaN). */
 __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, const Frame &f)
 {
     const V3 c = p.colour / (float)f.spp;
-    const int px = (int)(p.pxy & 0xffffu), py = (int)(p.pxy >> 16);
-    int out_row = py;
-    if (a.compact) {
-        const int band = py / a.band_rows;
-        out_row = ((band - a.band_first) / a.band_stride) * a.band_rows + (py - band * a.band_rows);
-    }
-    const size_t pixel = (size_t)out_row * (size_t)f.W + (size_t)px;
-    if (a.tile_cost) {
-        /* (first launch of a view) what this pixel cost, charged to its tile */
-        const int band = py / a.band_rows;
-        const int tile = ((band - a.band_first) / a.band_stride) * f.tiles_per_band + ((py - band * a.band_rows) >> 3) * a.tiles_x + (px >> 3);
-        atomicAdd(a.tile_cost + tile, p.frame_steps >> RT_FRAME_BITS);
-    }
+    const int tile = (int)(p.id >> 6), within = (int)(p.id & 63u);
+    int tx, ty, compact_row;
+    tile_place(a, f, tile, tx, ty, compact_row);
+    const int px = tx * 8 + (within & 7), py = ty * 8 + (within >> 3);
+    size_t pixel = (size_t)py * (size_t)f.W + (size_t)px;
+    if (a.compact) pixel = a.tile_list ? (size_t)p.id : (size_t)(compact_row + (within >> 3)) * (size_t)f.W + (size_t)px;
+    /* (first launch of a view) what this pixel cost, charged to its tile */
+    if (a.tile_cost) atomicAdd(a.tile_cost + tile, p.frame_steps >> RT_FRAME_BITS);
     p.mode = M_FETCH;
     if (a.partial) {
         float *dst = a.partial + ((size_t)(p.frame_steps & (unsigned)(RT_MAX_BATCH_FRAMES - 1)) * a.partial_plane + pixel) * 3;
-        dst[0] = rt_canon_nan(c.x); dst[1] = rt_canon_nan(c.y); dst[2] = rt_canon_nan(c.z);
+        dst[0] = c.x; dst[1] = c.y; dst[2] = c.z;
         return;
     }
     float *dst = a.out + pixel * 3;
@@ -367,6 +381,7 @@ __device__ __forceinline__ void px_shade(Px &p, const rt_kernel_args &a, const F
             p.thr = p.thr * tc;
         }
         p.bounce++;
+        p.frame_steps += (unsigned)(RT_COST_HIT * RT_MAX_BATCH_FRAMES);
     }
     p.mode = M_GEN;
     if (p.bounce >= f.limit) px_end_sample(p, a, f);
@@ -436,13 +451,11 @@ __device__ __forceinline__ void px_fetch(Px &p, Chunk &ch, const rt_kernel_args 
     if (!want) return;
     if (my_id < 0) { p.mode = M_DONE; return; }
     const int tile = my_id >> 6, within = my_id & 63;
-    const int band_local = tile / f.tiles_per_band;
-    const int in_band = tile - band_local * f.tiles_per_band;
-    const int band = a.band_first + band_local * a.band_stride;
-    const int ty = in_band / a.tiles_x, tx = in_band - ty * a.tiles_x;
+    int tx, ty, compact_row;
+    tile_place(a, f, tile, tx, ty, compact_row);
     const int px = tx * 8 + (within & 7);
-    const int py = band * a.band_rows + ty * 8 + (within >> 3);
-    p.pxy = ((unsigned)py << 16) | (unsigned)px;
+    const int py = ty * 8 + (within >> 3);
+    p.id = (unsigned)my_id;
     if (px < f.W && py < f.H) {
         /* src/raytracer.cu:123-127; Ray::set_direction_origin src/ray.cu:147-155,
          * cam_pixel_to_world src/camera.cu:24-29 */
@@ -474,6 +487,7 @@ template <bool HAS_MESH>
 __device__ __forceinline__ void px_gen(Px &p, const rt_kernel_args &a, const Lds &L)
 {
     V3 &o = p.o, &d = p.d;
+    p.frame_steps += (unsigned)(RT_COST_GEN * RT_MAX_BATCH_FRAMES);
     /* Ray::apply_antialias src/ray.cu:130-142 */
     if (a.antialias) {
         V3 off;

@@ -202,6 +202,44 @@ def reference_scene4(seed=2024, num_spheres=100):
     return objs, SKY_COLOUR
 
 
-CONFIG_SCENES = {"three_sphere": three_sphere, "cube": cube, "monkey": monkey,
+def soup6k(n=6000, seed=9):
+    """A mesh too large for a CU's LDS (the kernel's global-memory path): n random small triangles over a
+    checkerboard ground.  Synthetic: the reference ships no model of this size (its Mesh takes any triangle count,
+    src/objects.cu:780-787)."""
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform([-1.2, -0.6, 1.2], [1.2, 0.8, 3.5], (n, 3))
+    tris = (centres[:, None, :] + rng.normal(0, 0.05, (n, 3, 3))).astype(np.float32).reshape(n, 9)
+    objs = [("mesh", tris, ("standard", (0.8, 0.7, 0.6), 0.1)),
+            ("sphere", (0, -100.5, 1.5), 100, ("checkerboard", (0.9, 0.9, 0.9), (0.3, 0.3, 0.3), 4000, 0))]
+    return objs, SKY_COLOUR
+
+
+def bumpy_sphere(rings=160, segments=160, seed=5):
+    """A closed tessellated surface of 2 * rings * segments - 2 * segments triangles (50,880 by default: ~50 per leaf
+    of the reference's fixed-depth-10 BVH), radius 0.55 with a smooth radial bump, under the monkey scene's light and
+    over its ground.  Synthetic, for the beyond-LDS measurements."""
+    rng = np.random.default_rng(seed)
+    ph = rng.uniform(0, 2 * np.pi, 6)
+    th = np.linspace(0, np.pi, rings + 1)[:, None]
+    ps = np.linspace(0, 2 * np.pi, segments, endpoint=False)[None, :]
+    r = 0.55 * (1 + 0.08 * np.sin(5 * th + ph[0]) * np.cos(4 * ps + ph[1]) + 0.04 * np.sin(11 * th + ph[2]) * np.sin(9 * ps + ph[3]))
+    P = np.stack([r * np.sin(th) * np.cos(ps), r * np.cos(th) + 0 * ps, r * np.sin(th) * np.sin(ps)], axis=2) + np.array([0.1, 0.0, 1.7])
+    P = P.astype(np.float32)
+    tris = []
+    for i in range(rings):
+        for j in range(segments):
+            a, b = P[i, j], P[i, (j + 1) % segments]
+            c, d = P[i + 1, j], P[i + 1, (j + 1) % segments]
+            if i > 0:
+                tris.append(np.concatenate([a, b, d]))
+            if i < rings - 1:
+                tris.append(np.concatenate([a, d, c]))
+    objs = [("mesh", np.asarray(tris, np.float32), std((0.9, 0.85, 0.8), 0.05)),
+            ("sphere", (0, 1.2, 1.2), 0.5, ("emissive", (1, 1, 1), 6)),
+            ("sphere", (0, -100.5, 1.5), 100, std((0.5, 0.5, 0.5), 0.3))]
+    return objs, NO_SKY
+
+
+CONFIG_SCENES = {"three_sphere": three_sphere, "cube": cube, "monkey": monkey, "soup6k": soup6k, "sphere50k": bumpy_sphere,
                  "reference_scene0": reference_scene0, "reference_scene1": reference_scene1,
                  "reference_scene2": reference_scene2, "reference_scene3": reference_scene3, "reference_scene4": reference_scene4}

@@ -28,6 +28,49 @@ def test_configs_are_baseline_json_configs():
     assert b.weak_image(1920, 1080, 2) == (2720, 1530) and b.weak_image(1920, 1080, 4) == (3840, 2160) and b.weak_image(1920, 1080, 8) == (5424, 3051)
 
 
+def test_reference_default_workload_and_argument_defaults():
+    b = _bench()
+    # the reference's own defaults: scene 0, 1000x800 (src/camera.cu:4-5), 100 spp x 5 bounces (src/main.cu:318-330)
+    assert b.CONFIGS["ref0"] == ("reference_scene0", 1000, 800, 100, 5)
+    a = b.parse_args(["--config", "ref0"])
+    assert (a.scene, a.width, a.height, a.spp, a.limit) == ("reference_scene0", 1000, 800, 100, 5)
+    a = b.parse_args([])
+    assert (a.scene, a.width, a.height, a.spp, a.limit, a.gpus, a.partition) == ("monkey", 1920, 1080, 1024, 8, 1, "lists")
+    a = b.parse_args(["--config", "2", "--spp", "16", "--scene", "sphere50k"])
+    assert (a.scene, a.width, a.spp) == ("sphere50k", 1920, 16)
+
+
+def test_rccl_failure_is_a_failed_run_unless_the_fallback_is_asked_for(monkeypatch):
+    """a gloo measurement must never pass for an xGMI one: without --allow-gloo-fallback an RCCL initialisation
+    failure ends every rank with exit code 3"""
+    import pytest
+    import torch.distributed as dist
+    b = _bench()
+    calls = []
+
+    def fake_init(backend, **kw):
+        calls.append(backend)
+        if backend == "nccl":
+            raise RuntimeError("ncclInvalidUsage: duplicate GPU")
+
+    class Exit(Exception):
+        pass
+
+    def fake_exit(code):
+        raise Exit(code)
+    monkeypatch.setattr(dist, "init_process_group", fake_init)
+    monkeypatch.setattr(dist, "destroy_process_group", lambda: None)
+    monkeypatch.setattr(os, "_exit", fake_exit)
+    with pytest.raises(Exit) as e:
+        b.init_process_group(b.parse_args(["--gpus", "2"]), "cpu", 2)
+    assert e.value.args[0] == b.EXIT_NO_RCCL == 3 and calls == ["nccl"]
+    calls.clear()
+    backend, note = b.init_process_group(b.parse_args(["--gpus", "2", "--allow-gloo-fallback"]), "cpu", 2)
+    assert backend == "gloo" and calls == ["nccl", "gloo"] and "failed to initialise" in note
+    calls.clear()
+    assert b.init_process_group(b.parse_args(["--gpus", "2", "--backend", "gloo"]), "cpu", 2) == ("gloo", None) and calls == ["gloo"]
+
+
 def test_traffic_lookup_resolves_the_drivers_shape():
     b = _bench()
     # the driver runs --steps 20 --warmup 5: one launch of 20 frames; profiles/traffic.json must resolve it

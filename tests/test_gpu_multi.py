@@ -70,13 +70,19 @@ def test_render_multi_host_buffers(rt, orc, models_dir, name, W, H, n_ranks):
     assert data.frame_num == 3
     want = oracle_progressive(orc, objs, models_dir, cam.floats(), W, H, 4, limit, sky, [10, 11, 12])
     assert eq(data.previous_render, want)
+    # (the first call dealt the tiles out interleaved and measured them; this one owns them by cost)
     rt.render_multi(ctxs, scenes, cam, rd, data, [13])
     want = oracle_progressive(orc, objs, models_dir, cam.floats(), W, H, 4, limit, sky, [13], first_frame=3, prev=want)
     assert data.frame_num == 4 and eq(data.previous_render, want)
+    # ... and a third call in the steady state, two frames
+    rt.render_multi(ctxs, scenes, cam, rd, data, [14, 15])
+    want = oracle_progressive(orc, objs, models_dir, cam.floats(), W, H, 4, limit, sky, [14, 15], first_frame=4, prev=want)
+    assert data.frame_num == 6 and eq(data.previous_render, want)
     # and the single-context entry point gives the same image
     one = rt.VariableRenderData(W, H)
-    rt.render_frames(ctxs[0], scenes[0], cam, rd, one, [10, 11, 12, 13])
+    rt.render_frames(ctxs[0], scenes[0], cam, rd, one, [10, 11, 12, 13, 14, 15])
     assert eq(one.previous_render, want)
+    assert ctxs[0].peer_access(ctxs[-1]) == 1          # same GPU here; on a node: 1 = xGMI peer access is on
 
 
 def test_render_multi_device_and_gather(rt, orc, models_dir):
@@ -113,6 +119,108 @@ def test_render_multi_device_and_gather(rt, orc, models_dir):
     side.synchronize()
     assert eq(out.cpu().numpy(), want)
     assert dm.num_bands(H, 8) == 15
+
+
+@pytest.mark.parametrize("W,H", [(203, 117), (64, 64)])
+def test_tile_list_forms(rt, orc, models_dir, W, H):
+    """rt_tile_spec's tile-list form against the whole-frame render, bit for bit: a random subset of tiles (ragged
+    right and bottom edge tiles included) rendered (a) into a full-layout frame (other pixels untouched),
+    (b) compact, put back with rt_tiles_copy_device and with rt_gather's list form, (c) as a multi-frame launch in
+    place, compact and full layout, with and without cost hints; then the round trip frame -> compact -> frame."""
+    import torch
+    objs, sky = rt.scenes.monkey()
+    ctx = rt.Context(0)
+    scene = ctx.commit(rt.SceneObjects(objs))
+    cam, rd = rt.Camera(W, H), rt.RenderData(5, 8, True, sky)
+    st = torch.cuda.current_stream().cuda_stream
+    times = [77, 78, 79]
+    whole = torch.zeros((H, W, 3), device="cuda:0")
+    rt.render_device(ctx, scene, cam, rd, times[0], 0, whole.data_ptr(), stream=st)
+    whole3 = torch.zeros((H, W, 3), device="cuda:0")
+    rt.render_device_batch(ctx, scene, cam, rd, times, 0, whole3.data_ptr(), stream=st)
+    tx, ty = (W + 7) // 8, (H + 7) // 8
+    rng = np.random.default_rng(W)
+    ids = rng.permutation(tx * ty)[: (tx * ty) // 2].astype(np.uint32)
+    ids[0], ids[1] = tx * ty - 1, tx - 1                           # the two ragged corners are in
+    ids = np.unique(ids)
+    rng.shuffle(ids)
+    mask = np.zeros((ty * 8, tx * 8), bool)
+    for g in ids:
+        mask[(g // tx) * 8:(g // tx) * 8 + 8, (g % tx) * 8:(g % tx) * 8 + 8] = True
+    mask = torch.from_numpy(mask[:H, :W]).to("cuda:0")
+    # (a) full layout
+    a = torch.full((H, W, 3), -1.0, device="cuda:0")
+    rt.render_device(ctx, scene, cam, rd, times[0], 0, a.data_ptr(), stream=st, tile_list=ids)
+    torch.cuda.synchronize()
+    assert torch.equal(a[mask].view(torch.int32), whole[mask].view(torch.int32)) and bool((a[~mask] == -1.0).all())
+    tile_ids, cost = ctx.tile_costs()
+    assert np.array_equal(tile_ids, ids) and cost.min() > 0
+    # (b) compact + the two ways back into a frame
+    c = torch.full((len(ids) * 192,), -2.0, device="cuda:0")
+    rt.render_device(ctx, scene, cam, rd, times[0], 0, c.data_ptr(), compact=True, stream=st, tile_list=ids)
+    for how in ("copy", "gather"):
+        b = torch.full((H, W, 3), -1.0, device="cuda:0")
+        if how == "copy":
+            rt.tiles_copy_device(ctx, c.data_ptr(), b.data_ptr(), W, H, ids, True, st)
+        else:
+            rt.gather(ctx, b.data_ptr(), W, H, ctx, c.data_ptr(), stream=st, tile_list=ids)
+        torch.cuda.synchronize()
+        assert torch.equal(b.view(torch.int32), a.view(torch.int32)), how
+    # (c) three progressive frames in one launch, in place
+    for hints in (None, cost):
+        c3 = torch.zeros((len(ids) * 192,), device="cuda:0")
+        rt.render_device_batch(ctx, scene, cam, rd, times, 0, c3.data_ptr(), compact=True, stream=st, tile_list=ids, tile_cost=hints)
+        b = torch.full((H, W, 3), -1.0, device="cuda:0")
+        rt.tiles_copy_device(ctx, c3.data_ptr(), b.data_ptr(), W, H, ids, True, st)
+        f3 = torch.full((H, W, 3), -1.0, device="cuda:0")
+        rt.render_device_batch(ctx, scene, cam, rd, times, 0, f3.data_ptr(), stream=st, tile_list=ids, tile_cost=hints)
+        torch.cuda.synchronize()
+        for got in (b, f3):
+            assert torch.equal(got[mask].view(torch.int32), whole3[mask].view(torch.int32)) and bool((got[~mask] == -1.0).all())
+    # frame -> compact -> frame
+    back = torch.zeros((len(ids) * 192,), device="cuda:0")
+    rt.tiles_copy_device(ctx, back.data_ptr(), whole3.data_ptr(), W, H, ids, False, st)
+    again = torch.full((H, W, 3), -1.0, device="cuda:0")
+    rt.tiles_copy_device(ctx, back.data_ptr(), again.data_ptr(), W, H, ids, True, st)
+    torch.cuda.synchronize()
+    assert torch.equal(again[mask].view(torch.int32), whole3[mask].view(torch.int32))
+    # errors: a tile outside the image, a tile listed twice, costs without a list
+    with pytest.raises(ValueError):
+        rt.render_device(ctx, scene, cam, rd, 1, 0, a.data_ptr(), stream=st, tile_list=[tx * ty])
+    with pytest.raises(ValueError):
+        rt.render_device(ctx, scene, cam, rd, 1, 0, a.data_ptr(), stream=st, tile_list=[3, 3])
+    empty = torch.full((H, W, 3), -1.0, device="cuda:0")
+    rt.render_device(ctx, scene, cam, rd, 1, 0, empty.data_ptr(), stream=st, tile_list=[])        # renders nothing
+    torch.cuda.synchronize()
+    assert bool((empty == -1.0).all())
+
+
+def test_render_multi_device_balanced_lists(rt, orc, models_dir):
+    """rt_render_multi_device with band_rows = 0 (cost-balanced tile lists) on a caller stream, three calls (interleaved
+    + measuring, balanced, steady state), each against the oracle; then a call on ANOTHER stream of the root
+    (the staging areas are ordered behind the previous call's de-interleave by events, not by stream order)"""
+    import torch
+    objs, sky = rt.scenes.monkey()
+    W, H, spp, n = 232, 136, 3, 4
+    ctxs = [rt.Context(0) for _ in range(n)]
+    so = rt.SceneObjects(objs)
+    scenes = [c.commit(so) for c in ctxs]
+    cam, rd = rt.Camera(W, H), rt.RenderData(spp, 8, True, sky)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    frame = torch.full((H, W, 3), -1.0, device="cuda:0")
+    torch.cuda.synchronize()
+    calls = [([1, 2], s1), ([3], s1), ([4, 5, 6], s1), ([7], s2)]
+    done = 0
+    for times, s in calls:
+        if s is s2:
+            s1.synchronize()
+        rt.render_multi_device(ctxs, scenes, cam, rd, times, done, frame.data_ptr(), stream=s.cuda_stream)
+        done += len(times)
+    s2.synchronize()
+    for c in ctxs:
+        c.synchronize()
+    want = oracle_progressive(orc, objs, models_dir, cam.floats(), W, H, spp, 8, sky, [1, 2, 3, 4, 5, 6, 7])
+    assert eq(frame.cpu().numpy(), want)
 
 
 def test_render_multi_argument_errors(rt):

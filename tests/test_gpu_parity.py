@@ -167,21 +167,29 @@ def test_device_api_tiles_reassemble(rt, ctx):
         assert torch.equal(frame.contiguous().view(torch.int32), full.view(torch.int32))
 
 
-def test_full_size_properties(rt, orc, ctx, models_dir):
-    """BASELINE.json's headline image size (1920x1080, 8 bounces) at a small spp:
-    (1) partition invariance — bands rendered as 8 'ranks' reassemble bit-exactly to the
-        single-launch frame (a checksum of checksums over the parts equals the whole);
-    (2) bands chosen at random equal the oracle's rows for those bands;
-    (3) every value is finite and the untouched-rows contract holds."""
+@pytest.mark.parametrize("name", ["monkey", "three_sphere", "cube"])
+def test_full_size_properties(rt, orc, ctx, models_dir, name):
+    """BASELINE.json configs[1], [2], [3] at their real image size (1920x1080, 8 bounces; small spp) - the only
+    place the 256-thread kernels run at their real 5-6 workgroups per CU with 32,400 tiles:
+    (1) partition invariance - bands rendered as 8 'ranks' reassemble bit-exactly to the single-launch frame
+        (a checksum of checksums over the parts equals the whole);
+    (2) the same for the round-3 partition: cost-balanced TILE LISTS (costs measured by the first launch, 8 ranks
+        dealt longest-processing-time-first), each rank a 5-frame multi-frame launch with the costs as hints, tiles put
+        back with rt_tiles_copy_device - against 5 frames rendered frame by frame;
+    (3) bands chosen at random equal the oracle's rows for those bands;
+    (4) every value is finite."""
     import torch
     dist_mod = __import__("importlib").import_module("ray-tracer_amd.distributed")
-    objs, sky = rt.scenes.monkey()
+    objs, sky = rt.scenes.CONFIG_SCENES[name]()
     W, H, spp = 1920, 1080, 4
+    ctx = rt.Context(0)                      # a fresh context: views and their costs start empty
     scene = ctx.commit(rt.SceneObjects(objs))
     cam, rd = rt.Camera(W, H), rt.RenderData(spp, 8, True, sky)
     stream = torch.cuda.current_stream().cuda_stream
     full = torch.empty((H, W, 3), device="cuda:0")
     rt.render_device(ctx, scene, cam, rd, 12345, 0, full.data_ptr(), stream=stream)
+    ids, cost = ctx.tile_costs()             # the launch above was the first of its view: it measured the tiles
+    assert np.array_equal(ids, np.arange(240 * 135, dtype=np.uint32)) and cost.min() > 0
     world = 8
     stacked = torch.zeros((world, dist_mod.max_owned_rows(H, 8, world), W, 3), device="cuda:0")
     for r in range(world):
@@ -190,6 +198,27 @@ def test_full_size_properties(rt, orc, ctx, models_dir):
     frame = dist_mod.assemble(stacked, W, H, 8, world).contiguous()
     assert torch.equal(frame.view(torch.int32), full.view(torch.int32))
     assert torch.isfinite(full).all()
+    del stacked, frame
+    # (2) five progressive frames: frame by frame on the whole image ...
+    times = [12345 + i for i in range(5)]
+    x, y = full.clone(), torch.empty_like(full)
+    for i in range(1, 5):
+        rt.render_device(ctx, scene, cam, rd, times[i], i, y.data_ptr(), d_prev=x.data_ptr(), stream=stream)
+        x, y = y, x
+    # ... and as 8 cost-balanced tile lists, one multi-frame launch each
+    full_cost = np.zeros(240 * 135, np.uint32)
+    full_cost[ids] = cost
+    owner = rt.partition_tiles(W, H, world, full_cost)
+    lists = dist_mod.tile_lists(owner, world)
+    loads = np.array([full_cost[l].astype(np.int64).sum() for l in lists])
+    assert loads.max() - loads.min() <= int(full_cost.max())
+    out = torch.full((H, W, 3), -1.0, device="cuda:0")
+    buf = torch.zeros(dist_mod.compact_floats(lists), device="cuda:0")
+    for r in range(world):
+        rt.render_device_batch(ctx, scene, cam, rd, times, 0, buf.data_ptr(), compact=True, stream=stream, tile_list=lists[r], tile_cost=full_cost[lists[r]])
+        rt.tiles_copy_device(ctx, buf.data_ptr(), out.data_ptr(), W, H, lists[r], True, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int32), x.view(torch.int32))
     host = full.cpu().numpy()
     o = orc.Scene(objs, orc.MATH_DET, models_dir)
     rng = np.random.default_rng(11)
@@ -325,12 +354,7 @@ def test_textured_and_refractive_primitives(rt, orc, ctx, models_dir):
 
 def _big_mesh_scene(rt, n=6000):
     """a mesh of n random small triangles over a checkerboard ground: too large for a CU's LDS"""
-    rng = np.random.default_rng(9)
-    centres = rng.uniform([-1.2, -0.6, 1.2], [1.2, 0.8, 3.5], (n, 3))
-    tris = (centres[:, None, :] + rng.normal(0, 0.05, (n, 3, 3))).astype(np.float32).reshape(n, 9)
-    objs = [("mesh", tris, ("standard", (0.8, 0.7, 0.6), 0.1)),
-            ("sphere", (0, -100.5, 1.5), 100, ("checkerboard", (0.9, 0.9, 0.9), (0.3, 0.3, 0.3), 4000, 0))]
-    return objs, (0.8, 1.0, 1.0)
+    return rt.scenes.soup6k(n)
 
 
 def test_scene_larger_than_lds_uses_global_memory(rt, orc, ctx, models_dir):
@@ -407,31 +431,6 @@ def test_random_mixed_scenes(rt, orc, ctx, models_dir, seed):
     got = hip_render(rt, ctx, objs, W, H, spp, limit, sky, time_ms=1000 + seed)
     want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(W, H).floats(), W, H, spp, limit, sky, time_ms=1000 + seed)
     assert eq(got, want)
-
-
-@pytest.mark.parametrize("name,W,H,spp,limit", [("monkey", 160, 120, 6, 8), ("cube", 96, 64, 8, 8), ("reference_scene0", 125, 100, 4, 5)])
-def test_pooled_kernel_equals_oracle(rt, orc, models_dir, monkeypatch, name, W, H, spp, limit):
-    """the opt-in workgroup ray pool (RT_AMD_POOL=1, rt_render_pool_kernel): rays change waves, the
-    image must not change.  The switch is read when a context is created."""
-    monkeypatch.setenv("RT_AMD_POOL", "1")
-    pctx = rt.Context(0)
-    objs, sky = rt.scenes.CONFIG_SCENES[name]()
-    scene = pctx.commit(rt.SceneObjects(objs))
-    assert scene.info()["lds_bytes"] > 0
-    got = hip_render(rt, pctx, objs, W, H, spp, limit, sky)
-    want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(W, H).floats(), W, H, spp, limit, sky)
-    assert eq(got, want)
-    # several frames in a row through the same context (queues and flags start clean every launch)
-    again = hip_render(rt, pctx, objs, W, H, spp, limit, sky)
-    assert eq(again, want)
-    # ... and a multi-frame launch through the pooled kernel
-    data = rt.VariableRenderData(W, H)
-    rt.render_frames(pctx, scene, rt.Camera(W, H), rt.RenderData(spp, limit, True, sky), data, [12345, 12346, 12347])
-    o = orc.Scene(objs, orc.MATH_DET, models_dir)
-    prev = want
-    for i in (1, 2):
-        prev = o.render(rt.Camera(W, H).floats(), W, H, spp, limit, sky, time_ms=12345 + i, frame_num=i, prev=prev)
-    assert eq(data.previous_render, prev)
 
 
 @pytest.mark.parametrize("name", ["monkey", "three_sphere"])
