@@ -156,7 +156,9 @@ const char *rt_last_error(const rt_ctx *ctx);
 rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_scene **out);
 void rt_scene_destroy(rt_scene *s);
 /* introspection for tests: bytes of LDS per workgroup, node / triangle counts, the launch shape chosen for the
- * scene (workgroup size and how many workgroups are resident per CU) */
+ * scene (workgroup size and how many workgroups are resident per CU); scene_in_lds: 1 the whole scene is staged
+ * into LDS, 2 everything but the triangles (a mesh of more than ~1,500 triangles: its BVH still fits), 0 nothing
+ * (the kernel reads the scene from global memory / L2) */
 typedef struct rt_scene_info {
     int32_t num_objects, num_triangles, num_nodes, lds_bytes, scene_in_lds, threads_per_block, stack_entries, blocks_per_cu;
 } rt_scene_info;

@@ -128,7 +128,7 @@ struct rt_scene {
     FlatScene flat;          /* host copy (sizes, offsets) */
     int threads = 0;         /* workgroup size chosen for this scene */
     int blocks_per_cu = 1;   /* ... and how many of them are resident on a CU */
-    int scene_in_lds = 1;    /* 0: scene read from global memory (does not fit LDS) */
+    int scene_in_lds = RT_SCENE_LDS;    /* RT_SCENE_*: all of the scene in LDS, all but the triangles, or nothing */
     uint32_t uid = 0;        /* distinguishes scenes in the tile-order cache (addresses get reused) */
     size_t lds_bytes = 0;
 };
@@ -331,11 +331,29 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
             if (nb * (nt / 64) > best_waves) { best_waves = nb * (nt / 64); s->threads = nt; s->lds_bytes = lds; s->blocks_per_cu = nb; }
         }
     }
-    s->scene_in_lds = 1;
+    s->scene_in_lds = RT_SCENE_LDS;
+    const char *force_mode = getenv("RT_AMD_SCENE_MODE");           /* development: 0 forces the all-global kernel for scenes that do not fit LDS */
+    if (s->threads == 0 && s->flat.has_mesh && !(force_mode && atoi(force_mode) == RT_SCENE_GLOBAL)) {
+        /* The triangles do not fit, but everything before them in the blob may: BVH nodes (a depth-10 tree has at most
+         * 1,023, whatever the triangle count), object records, object list.  Then only the triangles are read from global
+         * memory (L2).  Worth it while at least half a CU's wave slots stay filled. */
+        const size_t prefix_bytes = (size_t)s->flat.off_tris * sizeof(rt_f4);
+        int best_waves = 0;
+        const int hybrid_candidates[3] = {1024, 768, 512};
+        for (int nt : hybrid_candidates) {
+            const size_t lds = prefix_bytes + per_thread * (size_t)nt;
+            if (lds > RT_LDS_LIMIT) continue;
+            int nb = rt_kernel_blocks_per_cu(1, RT_SCENE_HYBRID, nt, lds);
+            if (nb > RT_MAX_BLOCKS_PER_CU) nb = RT_MAX_BLOCKS_PER_CU;
+            if (nb < 1) nb = 1;
+            if (nb * (nt / 64) > best_waves) { best_waves = nb * (nt / 64); s->threads = nt; s->lds_bytes = lds; s->blocks_per_cu = nb; }
+        }
+        if (s->threads) s->scene_in_lds = RT_SCENE_HYBRID;
+    }
     if (s->threads == 0) {
         /* larger than a CU's LDS: the kernel reads the scene from global memory (L2-resident),
          * LDS holds only the traversal stacks */
-        s->scene_in_lds = 0;
+        s->scene_in_lds = RT_SCENE_GLOBAL;
         s->threads = s->flat.has_mesh ? 1024 : 256;
         s->lds_bytes = per_thread * (size_t)s->threads;
         if (s->lds_bytes > RT_LDS_LIMIT) {
@@ -344,7 +362,7 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
         }
         /* (a 256-thread workgroup is admitted at most 6 times at this kernel's SGPR count, whatever the API says:
          * MI355X_MICROARCH.md, residency; surplus workgroups would only queue behind the resident ones) */
-        int nb = rt_kernel_blocks_per_cu(s->flat.has_mesh ? 1 : 0, 0, s->threads, s->lds_bytes);
+        int nb = rt_kernel_blocks_per_cu(s->flat.has_mesh ? 1 : 0, RT_SCENE_GLOBAL, s->threads, s->lds_bytes);
         s->blocks_per_cu = nb < 1 ? 1 : (nb > RT_MAX_BLOCKS_PER_CU ? RT_MAX_BLOCKS_PER_CU : nb);
     }
     if (const char *e = getenv("RT_AMD_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) s->blocks_per_cu = v; }

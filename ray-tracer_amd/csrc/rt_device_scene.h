@@ -5,13 +5,16 @@
  * The reference keeps the scene as an array of 5,328-byte `Object` unions, 216-byte triangles
  * and 3,616-byte BVH nodes with one device allocation per node (SURVEY.md §8 sizes).  Here:
  *
- *   LDS-staged blob (one coalesced copy per workgroup, 16-byte units):
+ *   LDS-staged blob (one coalesced copy per workgroup, 16-byte units), in this order:
  *     nodes   64 B  both children's boxes + child references (one LDS round trip per step)
- *     tris    48 B  p0, side1, side2, unit normal            (reference src/objects.cu:175-186)
  *     objlds  64 B  per top-level object: what shading needs for a per-lane object index
  *     meshes  32 B  per mesh object: root box, root reference, object index
  *     objtab  48 B  the object list (rt_object) every lane walks in the same order: wave-uniform
  *                   LDS reads (broadcast) instead of vector global loads
+ *     tris    48 B  p0, side1, side2, unit normal            (reference src/objects.cu:175-186)
+ *   A scene that does not fit a CU's LDS keeps everything before the triangles there when that fits (a depth-10 tree is
+ *   at most 1,023 nodes = 64 KB, whatever the triangle count) and reads the triangles from global memory (L2); otherwise
+ *   the kernel reads every section from global memory (RT_SCENE_* below).
  *   global memory, read once per textured hit:
  *     tri_uv  24 B  per-triangle texture coordinates (only when a material needs UVs)
  *
@@ -29,6 +32,10 @@
 #include <stdint.h>
 
 #define RT_BVH_DEPTH 10              /* reference src/objects.cu:786 */
+/* where the render kernel reads the scene from (rt_scene_info.scene_in_lds) */
+#define RT_SCENE_GLOBAL 0            /* every section from global memory; LDS holds only the traversal stacks */
+#define RT_SCENE_LDS 1               /* the whole blob staged into LDS */
+#define RT_SCENE_HYBRID 2            /* everything but the triangles in LDS, the triangles from global memory */
 #define RT_STACK_ENTRIES RT_BVH_DEPTH /* at most one pending sibling per level below the root */
 #define RT_FRAME_BITS 5               /* a pixel keeps the index of its frame within the launch in this many bits */
 #define RT_MAX_BATCH_FRAMES (1 << RT_FRAME_BITS)   /* frames one launch can render */

@@ -682,14 +682,15 @@ std::string rt_flatten(const rt_scene_builder &b, FlatScene &out)
     if (n_tris > RT_REF_START_MASK) return "scene has too many triangles for the compact encoding";
     size_t n_meshes = 0;
     for (const HostObject &o : b.objs) n_meshes += o.type == RT_OBJ_MESH;
+    /* the triangles come last: a scene whose triangles do not fit a CU's LDS can still stage everything before them */
     out.off_nodes = 0;
-    out.off_tris = (int)(n_nodes * 4);
-    out.off_objlds = out.off_tris + (int)(n_tris * 3);
+    out.off_objlds = (int)(n_nodes * 4);
     out.off_meshes = out.off_objlds + (int)(b.objs.size() * RT_OBJLDS_F4);
     out.num_meshes = (int)n_meshes;
     out.off_objtab = out.off_meshes + (int)(n_meshes * 2);
+    out.off_tris = out.off_objtab + (int)(b.objs.size() * 3);
     static_assert(sizeof(rt_object) == 48, "rt_object is three 16-byte units");
-    out.blob.resize((size_t)out.off_objtab + b.objs.size() * 3);
+    out.blob.resize((size_t)out.off_tris + n_tris * 3);
     out.stack_entries = 1;
     out.num_nodes = (int)n_nodes;
     out.num_tris = (int)n_tris;

@@ -86,16 +86,18 @@ enum { ST_ITER = 0, ST_SHADE = 1, ST_SHADE_HIT = 2, ST_FETCH = 3, ST_GEN = 4, ST
 #define RT_STATS_FLUSH() do { } while (0)
 #endif
 
-/* SCENE_LDS = false is the fallback for scenes larger than a CU's LDS: the same code reads the
- * scene sections from global memory (they stay L2 / Infinity-Cache resident) and only the
- * traversal stack lives in LDS. */
+/* MODE (RT_SCENE_*): where the scene is read from.  RT_SCENE_LDS: the whole blob is staged into LDS.  For scenes larger
+ * than a CU's LDS the same code reads the triangles (RT_SCENE_HYBRID: the BVH nodes and the object records still fit) or
+ * every section (RT_SCENE_GLOBAL) from global memory - they stay L2 / Infinity-Cache resident.  (Requesting a leaf's next
+ * triangle before testing the current one, and testing two at a time, were measured on the 6,000- and 50,880-triangle
+ * scenes: no difference - the compiler keeps the tests sequential and four waves per SIMD already cover the L2 latency.) */
 /* Occupancy.  Built with -fno-slp-vectorize the kernel needs ~90 VGPRs (the SLP vectorizer's packed-f32 pairs cost
  * 128 and ~10 % of the time).  The 1024-thread workgroup of a large mesh scene is one per CU = four waves per SIMD,
  * whatever the registers (its LDS holds the scene and 1024 traversal stacks); the smaller workgroups - scenes without a
  * mesh, and mesh scenes small enough for several workgroups per CU - are register-bound, so they are compiled for
  * five waves per SIMD (<= 96 VGPRs; the allocator then lands on 79-80, which lets six be resident).  The launcher
  * asks the runtime how many workgroups of the chosen shape fit a CU (rt_kernel_blocks_per_cu). */
-template <int NT, bool HAS_MESH, bool SCENE_LDS>
+template <int NT, bool HAS_MESH, int MODE>
 __global__ __launch_bounds__(NT, NT == 1024 ? 4 : RT_SMALL_WG_WAVES) void rt_render_kernel(const rt_kernel_args a)
 {
     extern __shared__ v4f lds_raw[];
@@ -104,15 +106,16 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : RT_SMALL_WG_WAVES) void rt_ren
 
     Lds L;
     uint2 *stack;        /* [stack_entries + 1][NT] deferred sibling: (entry distance bits, reference) */
-    if (SCENE_LDS) {
-        /* stage the scene into LDS: coalesced 16-byte loads, one pass per workgroup */
-        for (int i = tid; i < a.blob_f4; i += NT) lds_raw[i] = ((const v4f *)a.blob)[i];
+    if (MODE != RT_SCENE_GLOBAL) {
+        /* stage the scene (or its part before the triangles) into LDS: coalesced 16-byte loads, one pass per workgroup */
+        const int staged = MODE == RT_SCENE_LDS ? a.blob_f4 : a.off_tris;
+        for (int i = tid; i < staged; i += NT) lds_raw[i] = ((const v4f *)a.blob)[i];
         L.nodes = lds_raw + a.off_nodes;
-        L.tris = lds_raw + a.off_tris;
         L.objs = lds_raw + a.off_objlds;
         L.meshes = lds_raw + a.off_meshes;
         L.objtab = lds_raw + a.off_objtab;
-        stack = (uint2 *)(lds_raw + a.blob_f4);
+        L.tris = MODE == RT_SCENE_LDS ? lds_raw + a.off_tris : (const v4f *)a.blob + a.off_tris;
+        stack = (uint2 *)(lds_raw + staged);
     } else {
         const v4f *g = (const v4f *)a.blob;
         L.nodes = g + a.off_nodes;
@@ -440,12 +443,12 @@ extern "C" hipError_t rt_launch_eval(int op, const uint32_t *in, uint32_t *out, 
 }
 
 /* ---- launchers (called from rt_capi.cpp) -------------------------------------------------- */
-template <int NT, bool HAS_MESH, bool SCENE_LDS>
+template <int NT, bool HAS_MESH, int MODE>
 static int rt_blocks_one(size_t lds_bytes)
 {
     int n = 0;
-    (void)hipFuncSetAttribute((const void *)rt_render_kernel<NT, HAS_MESH, SCENE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)rt_render_kernel<NT, HAS_MESH, SCENE_LDS>, NT, lds_bytes) != hipSuccess) n = 0;
+    (void)hipFuncSetAttribute((const void *)rt_render_kernel<NT, HAS_MESH, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)rt_render_kernel<NT, HAS_MESH, MODE>, NT, lds_bytes) != hipSuccess) n = 0;
     return n;
 }
 
@@ -453,40 +456,59 @@ static int rt_blocks_one(size_t lds_bytes)
  * runtime reports it; 0 if the shape is not built */
 extern "C" int rt_kernel_blocks_per_cu(int has_mesh, int scene_in_lds, int threads, size_t lds_bytes)
 {
-    if (!scene_in_lds) {
-        if (has_mesh && threads == 1024) return rt_blocks_one<1024, true, false>(lds_bytes);
-        if (!has_mesh && threads == 256) return rt_blocks_one<256, false, false>(lds_bytes);
+    if (scene_in_lds == RT_SCENE_GLOBAL) {
+        if (has_mesh && threads == 1024) return rt_blocks_one<1024, true, RT_SCENE_GLOBAL>(lds_bytes);
+        if (!has_mesh && threads == 256) return rt_blocks_one<256, false, RT_SCENE_GLOBAL>(lds_bytes);
         return 0;
     }
+    if (scene_in_lds == RT_SCENE_HYBRID) {
+        if (!has_mesh) return 0;
+        switch (threads) {
+            case 512: return rt_blocks_one<512, true, RT_SCENE_HYBRID>(lds_bytes);
+            case 768: return rt_blocks_one<768, true, RT_SCENE_HYBRID>(lds_bytes);
+            case 1024: return rt_blocks_one<1024, true, RT_SCENE_HYBRID>(lds_bytes);
+            default: return 0;
+        }
+    }
     switch (threads) {
-        case 256: return has_mesh ? rt_blocks_one<256, true, true>(lds_bytes) : rt_blocks_one<256, false, true>(lds_bytes);
-        case 512: return has_mesh ? rt_blocks_one<512, true, true>(lds_bytes) : rt_blocks_one<512, false, true>(lds_bytes);
-        case 768: return has_mesh ? rt_blocks_one<768, true, true>(lds_bytes) : rt_blocks_one<768, false, true>(lds_bytes);
-        case 1024: return has_mesh ? rt_blocks_one<1024, true, true>(lds_bytes) : rt_blocks_one<1024, false, true>(lds_bytes);
+        case 256: return has_mesh ? rt_blocks_one<256, true, RT_SCENE_LDS>(lds_bytes) : rt_blocks_one<256, false, RT_SCENE_LDS>(lds_bytes);
+        case 512: return has_mesh ? rt_blocks_one<512, true, RT_SCENE_LDS>(lds_bytes) : rt_blocks_one<512, false, RT_SCENE_LDS>(lds_bytes);
+        case 768: return has_mesh ? rt_blocks_one<768, true, RT_SCENE_LDS>(lds_bytes) : rt_blocks_one<768, false, RT_SCENE_LDS>(lds_bytes);
+        case 1024: return has_mesh ? rt_blocks_one<1024, true, RT_SCENE_LDS>(lds_bytes) : rt_blocks_one<1024, false, RT_SCENE_LDS>(lds_bytes);
         default: return 0;
     }
 }
 
-template <int NT, bool HAS_MESH, bool SCENE_LDS>
+template <int NT, bool HAS_MESH, int MODE>
 static void rt_launch_one(const rt_kernel_args *args, int blocks, size_t lds_bytes, hipStream_t stream)
 {
-    (void)hipFuncSetAttribute((const void *)rt_render_kernel<NT, HAS_MESH, SCENE_LDS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((rt_render_kernel<NT, HAS_MESH, SCENE_LDS>), dim3(blocks), dim3(NT), lds_bytes, stream, *args);
+    (void)hipFuncSetAttribute((const void *)rt_render_kernel<NT, HAS_MESH, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((rt_render_kernel<NT, HAS_MESH, MODE>), dim3(blocks), dim3(NT), lds_bytes, stream, *args);
 }
 
 extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh, int scene_in_lds, int threads, int blocks, size_t lds_bytes, hipStream_t stream)
 {
-    if (!scene_in_lds) {
+    if (scene_in_lds == RT_SCENE_GLOBAL) {
         /* global-memory scene: one shape per mesh flag is enough */
-        if (has_mesh && threads == 1024) rt_launch_one<1024, true, false>(args, blocks, lds_bytes, stream);
-        else if (!has_mesh && threads == 256) rt_launch_one<256, false, false>(args, blocks, lds_bytes, stream);
+        if (has_mesh && threads == 1024) rt_launch_one<1024, true, RT_SCENE_GLOBAL>(args, blocks, lds_bytes, stream);
+        else if (!has_mesh && threads == 256) rt_launch_one<256, false, RT_SCENE_GLOBAL>(args, blocks, lds_bytes, stream);
         else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
+    if (scene_in_lds == RT_SCENE_HYBRID) {
+        if (!has_mesh) return hipErrorInvalidValue;
+        switch (threads) {
+            case 512: rt_launch_one<512, true, RT_SCENE_HYBRID>(args, blocks, lds_bytes, stream); break;
+            case 768: rt_launch_one<768, true, RT_SCENE_HYBRID>(args, blocks, lds_bytes, stream); break;
+            case 1024: rt_launch_one<1024, true, RT_SCENE_HYBRID>(args, blocks, lds_bytes, stream); break;
+            default: return hipErrorInvalidValue;
+        }
         return hipGetLastError();
     }
 #define RT_CASE(NTV)                                                                                   \
     case NTV:                                                                                          \
-        if (has_mesh) rt_launch_one<NTV, true, true>(args, blocks, lds_bytes, stream);                 \
-        else rt_launch_one<NTV, false, true>(args, blocks, lds_bytes, stream);                         \
+        if (has_mesh) rt_launch_one<NTV, true, RT_SCENE_LDS>(args, blocks, lds_bytes, stream);         \
+        else rt_launch_one<NTV, false, RT_SCENE_LDS>(args, blocks, lds_bytes, stream);                 \
         break;
     switch (threads) {
         RT_CASE(256)

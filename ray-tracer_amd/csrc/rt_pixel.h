@@ -52,7 +52,7 @@ __device__ __forceinline__ float normal_num(uint32_t &state)
     return rho * rt_cosf(theta);
 }
 
-/* the scene sections (LDS, or global memory for scenes larger than a CU's LDS) */
+/* the scene sections (LDS, or global memory for what of a large scene does not fit a CU's LDS) */
 struct Lds {
     const v4f *nodes;
     const v4f *tris;

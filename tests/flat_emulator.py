@@ -66,8 +66,9 @@ def tri_test(tris, idx, o, d):
 class FlatScene:
     def __init__(self, flat):
         self.blob = flat["blob"]
-        self.nodes = self.blob[flat["off_nodes"]:flat["off_tris"]]
-        self.tris = self.blob[flat["off_tris"]:flat["off_objlds"]]
+        # blob order: nodes, objlds, meshes, objtab, tris (the triangles last: rt_device_scene.h)
+        self.nodes = self.blob[flat["off_nodes"]:flat["off_objlds"]]
+        self.tris = self.blob[flat["off_tris"]:flat["off_tris"] + 3 * flat["num_triangles"]]
         self.objlds = self.blob[flat["off_objlds"]:flat["off_meshes"]]
         self.objects = flat["objects"]
         self.max_stack = 0

@@ -357,16 +357,29 @@ def _big_mesh_scene(rt, n=6000):
     return rt.scenes.soup6k(n)
 
 
-def test_scene_larger_than_lds_uses_global_memory(rt, orc, ctx, models_dir):
-    """maximum sizes: a 6,000-triangle mesh (BVH + triangles ~ 350 KB) cannot be staged into a
-    CU's 160 KB LDS; the kernel then reads the scene from global memory and must still match"""
+def test_scene_larger_than_lds_uses_global_memory(rt, orc, ctx, models_dir, monkeypatch):
+    """maximum sizes: a 6,000-triangle mesh (BVH + triangles ~ 350 KB) cannot be staged into a CU's 160 KB LDS.  Its BVH
+    and records can (64 KB): the kernel then reads only the triangles from global memory (hybrid).  Three meshes' BVHs
+    cannot either: everything is read from global memory.  Both must match the oracle; and so must the all-global kernel on
+    the one-mesh scene (RT_AMD_SCENE_MODE=0, the development override)."""
     n = 6000
     objs, sky = _big_mesh_scene(rt, n)
     scene = ctx.commit(rt.SceneObjects(objs))
     info = scene.info()
-    assert info["scene_in_lds"] == 0 and info["num_triangles"] == n
+    assert info["scene_in_lds"] == 2 and info["num_triangles"] == n      # BVH + records in LDS, triangles from L2
     got = hip_render(rt, ctx, objs, 160, 96, 4, 6, sky)
     want = orc.Scene(objs, orc.MATH_DET, models_dir).render(rt.Camera(160, 96).floats(), 160, 96, 4, 6, sky)
+    assert eq(got, want)
+    monkeypatch.setenv("RT_AMD_SCENE_MODE", "0")
+    assert ctx.commit(rt.SceneObjects(objs)).info()["scene_in_lds"] == 0
+    assert eq(hip_render(rt, ctx, objs, 160, 96, 4, 6, sky), want)
+    monkeypatch.delenv("RT_AMD_SCENE_MODE")
+    # three meshes of 2,000 triangles each: 3 x 1,023 nodes do not fit next to the traversal stacks
+    tris = np.asarray(objs[0][1]).reshape(-1, 9)
+    three = [("mesh", tris[i::3], objs[0][2]) for i in range(3)] + list(objs[1:])
+    assert ctx.commit(rt.SceneObjects(three)).info()["scene_in_lds"] == 0
+    got = hip_render(rt, ctx, three, 128, 80, 3, 5, sky)
+    want = orc.Scene(three, orc.MATH_DET, models_dir).render(rt.Camera(128, 80).floats(), 128, 80, 3, 5, sky)
     assert eq(got, want)
 
 

@@ -32,13 +32,15 @@ def kernel_notes(rt, tmp_path):
 def test_render_kernel_register_budget(rt, tmp_path):
     notes = kernel_notes(rt, tmp_path)
     render = {n: v for n, v in notes.items() if "rt_render_kernel" in n}
-    # every instantiation the launcher can pick (rt_kernel.hip rt_launch_render): NT x HAS_MESH for LDS scenes + two global ones
-    assert len(render) == 10, sorted(render)
+    # every instantiation the launcher can pick (rt_kernel.hip rt_launch_render): NT x HAS_MESH for LDS scenes, three hybrid
+    # shapes (BVH in LDS, triangles from L2) and two all-global ones
+    assert len(render) == 13, sorted(render)
     report = []
     for name, v in sorted(render.items()):
-        m = re.search(r"ILi(\d+)ELb([01])ELb([01])E", name)
-        nt, mesh, lds = int(m.group(1)), m.group(2) == "1", m.group(3) == "1"
-        report.append("NT=%4d mesh=%d lds=%d: %s" % (nt, mesh, lds, v))
+        m = re.search(r"ILi(\d+)ELb([01])ELi([012])E", name)
+        nt, mesh, mode = int(m.group(1)), m.group(2) == "1", int(m.group(3))
+        lds = mode == 1
+        report.append("NT=%4d mesh=%d mode=%d: %s" % (nt, mesh, mode, v))
         assert v["vgpr_spill_count"] == 0 and v["agpr_count"] == 0, (name, v)
         # the two shapes the three BASELINE 1080p configurations run: no scratch at all
         if lds and (nt == 256 or (nt == 1024 and mesh)):
@@ -51,7 +53,7 @@ def test_render_kernel_register_budget(rt, tmp_path):
             # one 1024-thread workgroup per CU = four waves per SIMD: 128 registers each
             assert v["vgpr_count"] <= 128, (name, v)
         # SGPR spills (to VGPR lanes, not memory) are tolerated but recorded: they sit outside the traversal loops
-        assert v["sgpr_spill_count"] <= 64, (name, v)
+        assert v["sgpr_spill_count"] <= (40 if lds else 96), (name, v)
     print("\n".join(report))
     small = {n: v for n, v in notes.items() if "rt_render_kernel" not in n}
     assert all(v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 for v in small.values()), small

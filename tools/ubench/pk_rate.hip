@@ -6,7 +6,6 @@
 #include <cstdio>
 typedef float v2f __attribute__((ext_vector_type(2)));
 #define N 4096
-#define CHAINS 8
 #define OP_MUL 0
 #define OP_PK_MUL 1
 #define OP_PK_ADD 2
@@ -15,7 +14,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define OP_MAX3 5
 #define OP_FMA 6
 #define OP_MUL_F64 7
-template <int OP>
+template <int OP, int CHAINS>
 __global__ void k(float *out, unsigned long long *cyc, float x)
 {
     v2f a[CHAINS];
@@ -45,24 +44,31 @@ __global__ void k(float *out, unsigned long long *cyc, float x)
     out[threadIdx.x] = s;
     if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
-template <int OP>
-static void run(const char *name, float *out, unsigned long long *cyc)
+template <int OP, int CHAINS>
+static void run1(const char *name, float *out, unsigned long long *cyc)
 {
     for (int waves = 4; waves <= 16; waves *= 2) {      // waves in the one workgroup = on the one CU; 4 SIMDs
         unsigned long long h = 0;
         for (int r = 0; r < 2; r++) {
-            hipLaunchKernelGGL(k<OP>, dim3(1), dim3(64 * waves), 0, 0, out, cyc, 1.0f);
-            hipDeviceSynchronize();
-            hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+            hipLaunchKernelGGL((k<OP, CHAINS>), dim3(1), dim3(64 * waves), 0, 0, out, cyc, 1.0f);
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
         }
         const double per_simd = waves / 4.0;
-        printf("%-12s %d waves/SIMD: %.2f cycles per instruction per wave, %.3f wave-instructions per cycle per SIMD\n", name, (int)per_simd, (double)h / N, per_simd * N / (double)h);
+        printf("%-12s %s, %d waves/SIMD: %.2f cycles per instruction per wave, %.3f wave-instructions per cycle per SIMD\n", name,
+               CHAINS == 1 ? "ONE dependent chain " : "8 independent chains", (int)per_simd, (double)h / N, per_simd * N / (double)h);
     }
+}
+template <int OP>
+static void run(const char *name, float *out, unsigned long long *cyc)
+{
+    run1<OP, 8>(name, out, cyc);
+    run1<OP, 1>(name, out, cyc);
 }
 int main()
 {
     float *out; unsigned long long *cyc;
-    hipMalloc(&out, 8192); hipMalloc(&cyc, 8);
+    (void)hipMalloc(&out, 8192); (void)hipMalloc(&cyc, 8);
     run<OP_MUL>("v_mul_f32", out, cyc);
     run<OP_FMA>("v_fma_f32", out, cyc);
     run<OP_MIN>("v_min_f32", out, cyc);
