@@ -157,6 +157,21 @@ def cpu_model():
     return "unknown"
 
 
+def cgroup_cpu_quota():
+    """cores the container's cgroup grants (cpu.max quota / period), or None: a box can show 256 threads in its affinity
+    mask and still be throttled to a 16-core share"""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                return None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            q = float(txt[0])
+            return None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
 def cpu_baseline(rt, objs, sky, W, H, limit, spp_full, budget_s=12.0):
     """The oracle (det mode) on a bounded sample of the workload: the full frame at a reduced spp (per-sample
     work does not depend on spp).  Three figures: on the 16-thread CPU share of a one-GPU box (the headline
@@ -182,7 +197,7 @@ def cpu_baseline(rt, objs, sky, W, H, limit, spp_full, budget_s=12.0):
     value, spp, dt, st = timed(threads, budget_s)
     out = {"value": value, "unit": "Msamples/s", "cores": threads, "kind": "port",
            "sample": "%dx%d full frame at %d spp of %d, %d bounces, %.1f s" % (W, H, spp, spp_full, limit, dt),
-           "cpu_model": cpu_model(), "host_threads_available": avail}
+           "cpu_model": cpu_model(), "host_threads_available": avail, "cgroup_cpu_quota_cores": cgroup_cpu_quota()}
     if avail > threads:
         v_all, spp_all, dt_all, _ = timed(avail, budget_s)
         out["all_threads"] = {"value": v_all, "unit": "Msamples/s", "cores": avail,

@@ -225,8 +225,8 @@ int32_t rt_tile_owned_rows(const rt_tile_spec *tiles, int32_t height);
 /* What the tiles of this context's current view cost: the first launch of a view (scene, camera, image size,
  * tile spec) adds up, per tile, the work of its pixels (traversal steps, generated rays and shaded hits,
  * weighted); this call waits for that launch and copies the figures out: tile_ids[i] = the tile's index in
- * the image (ty * ceil(width / 8) + tx), costs[i] its cost, for i < *count (= the tiles of that launch, at
- * most `capacity`).  RT_ERR_INVALID if no launch of the current view has collected costs.  The reference
+ * the image (ty * ceil(width / 8) + tx), costs[i] its cost (opaque units; bit 0 says whether a ray of the tile
+ * entered a mesh), for i < *count (= the tiles of that launch, at most `capacity`).  RT_ERR_INVALID if no launch of the current view has collected costs.  The reference
  * has no counterpart (one GPU, one thread per pixel, src/dispatch.cu:136-139); this is what lets N GPUs
  * share a frame by cost instead of by area. */
 rt_status rt_tile_costs(rt_ctx *ctx, uint32_t *tile_ids, uint32_t *costs, int32_t capacity, int32_t *count);

@@ -161,8 +161,22 @@ uint64_t fnv1a(const void *data, size_t bytes, uint64_t h = 1469598103934665603u
     return h;
 }
 
+#define RT_DEV_LIST_CACHE 64
+
+/* Room for `count` more cached tile lists on ctx's GPU (the current device).  A full cache is emptied as a whole - after
+ * waiting for the device, so that no queued kernel still reads a list - which invalidates every pointer
+ * device_tile_list has handed out: a caller that holds several at once (rt_render_multi_device) reserves first. */
+void reserve_tile_lists(rt_ctx *ctx, size_t count)
+{
+    if (ctx->dev_lists.size() + count <= RT_DEV_LIST_CACHE) return;
+    (void)hipDeviceSynchronize();
+    for (DevList &dl : ctx->dev_lists) (void)hipFree(dl.d);
+    ctx->dev_lists.clear();
+}
+
 /* `list` (host) on ctx's GPU.  A new list is uploaded on `stream` and the call waits for the upload (the source is the
- * caller's memory); a list seen before costs a hash. */
+ * caller's memory); a list seen before costs a hash.  The pointer stays valid until the cache is next emptied
+ * (reserve_tile_lists): use it in launches queued before the next call, or reserve room for all the lists needed. */
 rt_status device_tile_list(rt_ctx *ctx, const uint32_t *list, int n, hipStream_t stream, const uint32_t **out)
 {
     *out = nullptr;
@@ -170,11 +184,7 @@ rt_status device_tile_list(rt_ctx *ctx, const uint32_t *list, int n, hipStream_t
     const uint64_t h = fnv1a(list, (size_t)n * 4);
     for (const DevList &dl : ctx->dev_lists)
         if (dl.hash == h && dl.n == n) { *out = dl.d; return RT_OK; }
-    if (ctx->dev_lists.size() >= 64) {
-        /* (hipFree waits for the device: nothing can still be reading the old lists) */
-        for (DevList &dl : ctx->dev_lists) (void)hipFree(dl.d);
-        ctx->dev_lists.clear();
-    }
+    reserve_tile_lists(ctx, 1);
     DevList dl;
     dl.hash = h; dl.n = n;
     RT_HIP(ctx, hipMalloc((void **)&dl.d, (size_t)n * 4), "allocating a tile list");
@@ -466,15 +476,17 @@ static int launch_blocks(const rt_ctx *ctx, const rt_scene *scene, int num_tiles
 }
 
 /* the schedule of a multi-frame launch (see its use in render_frames): `order` is the launch's tile order
- * (any permutation of 0..n-1; ties in cost keep it), cost[t] the measured cost of tile t */
+ * (any permutation of 0..n-1; ties in cost keep it), cost[t] the measured cost of tile t - bit 0 set if a ray of the
+ * tile entered a mesh: those are the long jobs; the others (sky, ground) follow frame by frame */
 static void build_job_order(const std::vector<uint32_t> &order, const std::vector<uint32_t> &cost, uint32_t top_max, uint32_t frames,
                             std::vector<uint32_t> &jobs)
 {
     const uint32_t n = (uint32_t)order.size();
-    std::vector<uint32_t> idx(order);
+    std::vector<uint32_t> idx;
+    idx.reserve(n);
+    for (uint32_t t : order) if (cost[t] & 1u) idx.push_back(t);
     std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
-    uint32_t top = top_max < n ? top_max : n;
-    while (top > 0 && cost[idx[top - 1]] == 0) top--;
+    const uint32_t top = top_max < (uint32_t)idx.size() ? top_max : (uint32_t)idx.size();
     jobs.clear();
     jobs.reserve((size_t)n * frames);
     /* by decreasing cost, the frames of a tile together */
@@ -515,10 +527,11 @@ rt_status read_costs_and_refine(rt_ctx *ctx, hipStream_t stream)
     }
     if (ctx->use_order && ctx->heavy_top > 0) {
         const std::vector<uint32_t> &cost = ctx->cost_host;
-        std::vector<uint32_t> idx(ctx->order_host);
+        std::vector<uint32_t> idx;
+        idx.reserve(n);
+        for (uint32_t t : ctx->order_host) if (cost[t] & 1u) idx.push_back(t);          /* tiles with a ray in a mesh */
         std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
-        uint32_t top = (uint32_t)ctx->heavy_top < n ? (uint32_t)ctx->heavy_top : n;
-        while (top > 0 && cost[idx[top - 1]] == 0) top--;
+        const uint32_t top = (uint32_t)ctx->heavy_top < (uint32_t)idx.size() ? (uint32_t)ctx->heavy_top : (uint32_t)idx.size();
         std::vector<char> taken(n, 0);
         std::vector<uint32_t> merged;
         merged.reserve(n);
@@ -1163,6 +1176,9 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
         (void)peer_access(c, root);      /* direct xGMI copies instead of staging through the host when the platform allows */
     }
     RT_HIP(root, hipSetDevice(root->device), "selecting device");
+    /* this call holds every rank's list on the root's GPU at once (the copies to and from the frame), and rank 0's launch
+     * looks its own up as well: make room now, so that the cache is not emptied under the pointers */
+    if (band_rows == 0) reserve_tile_lists(root, (size_t)n_ranks + 2);
 
     /* ---- who renders what -------------------------------------------------------------------------- */
     BandLayout L;

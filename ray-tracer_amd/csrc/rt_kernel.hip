@@ -193,6 +193,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : RT_SMALL_WG_WAVES) void rt_ren
                 if (!rh || rd > RT_INF_F || ((root_ref & RT_REF_CHAIN) && !(rd < RT_INF_F))) continue;
                 cur = root_ref; sp = 0; w_best = RT_INF_F; w_prim = -1;
                 p.mode = M_WAIT;
+                p.frame_steps |= 0x80000000u;           /* (cost bookkeeping: this pixel traverses) */
                 RT_STAT(ST_MESH_START);
             }
 

@@ -139,8 +139,9 @@ struct Px {
     float cur_n;                 /* Ray::current_refractive_index src/ray.cu:56,144 */
     float best_t;
     int best_obj, best_prim, next_mesh;
-    /* bits RT_FRAME_BITS-1..0: which frame of a multi-frame launch this pixel belongs to; the bits above: the traversal
-     * macro steps it has cost so far, reported per tile when the launch collects costs (tile_cost) */
+    /* bits RT_FRAME_BITS-1..0: which frame of a multi-frame launch this pixel belongs to; bits 30..RT_FRAME_BITS: what it has
+     * cost so far (RT_COST_* units), reported per tile when the launch collects costs (tile_cost); bit 31: one of its rays
+     * has entered a mesh */
     unsigned frame_steps;
 #ifdef RT_COSTMAP
     /* development build (tools/costmap.py): the frame holds, per pixel, (own traversal steps,
@@ -229,7 +230,12 @@ __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, 
     size_t pixel = (size_t)py * (size_t)f.W + (size_t)px;
     if (a.compact) pixel = a.tile_list ? (size_t)p.id : (size_t)(compact_row + (within >> 3)) * (size_t)f.W + (size_t)px;
     /* (first launch of a view) what this pixel cost, charged to its tile */
-    if (a.tile_cost) atomicAdd(a.tile_cost + tile, p.frame_steps >> RT_FRAME_BITS);
+    if (a.tile_cost) {
+        /* cost units in bits 31..1 of the tile's sum; bit 0: some pixel of the tile traversed a mesh (those tiles are
+         * the long jobs the schedule puts first, rt_capi.cpp build_job_order) */
+        atomicAdd(a.tile_cost + tile, ((p.frame_steps & 0x7fffffffu) >> RT_FRAME_BITS) << 1);
+        if (p.frame_steps >> 31) atomicOr(a.tile_cost + tile, 1u);
+    }
     p.mode = M_FETCH;
     if (a.partial) {
         float *dst = a.partial + ((size_t)(p.frame_steps & (unsigned)(RT_MAX_BATCH_FRAMES - 1)) * a.partial_plane + pixel) * 3;

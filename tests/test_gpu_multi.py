@@ -223,6 +223,34 @@ def test_render_multi_device_balanced_lists(rt, orc, models_dir):
     assert eq(frame.cpu().numpy(), want)
 
 
+def test_tile_list_cache_turnover_during_a_multi_call(rt, orc, models_dir):
+    """Found by tests/soak/soak_partition.py (seed 100026): a context caches the tile lists it has uploaded (64 of them) and
+    empties the cache when it is full; rt_render_multi_device holds every rank's list on the root at once, and a turnover in
+    the middle of the call left it with pointers to freed lists.  Here the root's cache is brought to the brim with 61 other
+    lists first, so the very next multi-GPU call crosses the limit."""
+    import torch
+    objs, sky = rt.scenes.cube()
+    W, H, spp, n = 88, 64, 2, 5
+    ctxs = [rt.Context(0) for _ in range(n)]
+    so = rt.SceneObjects(objs)
+    scenes = [c.commit(so) for c in ctxs]
+    cam, rd = rt.Camera(W, H), rt.RenderData(spp, 8, True, sky)
+    st = torch.cuda.current_stream().cuda_stream
+    frame = torch.zeros((H, W, 3), device="cuda:0")
+    scratch = torch.zeros((H, W, 3), device="cuda:0")
+    buf = torch.zeros(((W // 8) * (H // 8) * 192,), device="cuda:0")
+    want = None
+    done = 0
+    for rnd, times in enumerate(([5], [6, 7], [8])):
+        for k in range(61):                              # 61 distinct lists on the root between the multi-GPU calls
+            rt.tiles_copy_device(ctxs[0], buf.data_ptr(), scratch.data_ptr(), W, H, [(k + 61 * rnd) % 88, (k * 7 + rnd) % 88 if (k * 7 + rnd) % 88 != (k + 61 * rnd) % 88 else 87 - (k % 80)], False, st)
+        rt.render_multi_device(ctxs, scenes, cam, rd, times, done, frame.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        want = oracle_progressive(orc, objs, models_dir, cam.floats(), W, H, spp, 8, sky, times, first_frame=done, prev=want)
+        done += len(times)
+        assert eq(frame.cpu().numpy(), want), rnd
+
+
 def test_render_multi_argument_errors(rt):
     objs, sky = rt.scenes.three_sphere()
     a, b = rt.Context(0), rt.Context(0)

@@ -5,7 +5,9 @@ d = sys.argv[1]
 scenes = sys.argv[2:] or ["monkey", "three_sphere", "cube"]
 print("# rocprofv3 summary of", d, "(collected with tools/profile_all.sh)")
 for s in scenes:
-    print("\n" + "=" * 100 + "\n# scene %s, 1920x1080, 1024 spp, 8 bounces" % s)
+    what = {"reference_scene0": "1000x800, 100 spp, 5 bounces (the reference's default workload)", "sphere50k": "1920x1080, 16 spp, 8 bounces (50,880 triangles: BVH in LDS, triangles from L2)",
+            "soup6k": "1920x1080, 64 spp, 8 bounces (6,000 triangles: BVH in LDS, triangles from L2)"}.get(s, "1920x1080, 1024 spp, 8 bounces")
+    print("\n" + "=" * 100 + "\n# scene %s, %s" % (s, what))
     for f in glob.glob(os.path.join(d, "stats_" + s, "**", "*_kernel_stats.csv"), recursive=True):
         print("\n## kernel stats (rocprofv3 --kernel-trace --stats -- python3 bench.py --config N --steps 20 --warmup 5 --no-cpu-baseline --no-frame-by-frame-leg)")
         for i, row in enumerate(csv.reader(open(f))):
