@@ -311,7 +311,8 @@ def main():
         part = {"kind": "tile lists (cost-balanced)" if use_lists else "bands of 8 rows"}
 
         def run(n, record, lists, hints, local, gathered):
-            spec = dict(tile_list=lists[rank], tile_cost=hints, compact=True) if lists is not None else dict(band_first=rank, band_stride=world, compact=True)
+            spec = dict(tile_list=lists[rank], tile_cost=hints[0] if hints else None, tile_peak=hints[1] if hints else None, compact=True) if lists is not None \
+                else dict(band_first=rank, band_stride=world, compact=True)
 
             def collect():
                 if lists is not None:
@@ -350,9 +351,9 @@ def main():
             lists0 = dm.tile_lists(dm.initial_ownership(W, H, world), world)
             local, gathered = buffers(lists0)
             run(max(warmup, 1), False, lists0, None, local, gathered)
-            owner, cost = dm.balanced_ownership(ctx, W, H, lists0, rank, world, device=dev)
+            owner, cost, peak = dm.balanced_ownership(ctx, W, H, lists0, rank, world, device=dev)
             lists = dm.tile_lists(owner, world)
-            hints = cost[lists[rank]]
+            hints = (cost[lists[rank]], peak[lists[rank]])
             loads = [int(cost[l].astype(np.int64).sum()) for l in lists]
             part.update({"tiles_per_rank": [int(len(l)) for l in lists], "cost_share_per_rank": [round(x / float(max(1, sum(loads))), 4) for x in loads]})
             local, gathered = buffers(lists)

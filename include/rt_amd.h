@@ -188,9 +188,10 @@ rt_status rt_render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_camera *
  * to back (band k of this rank at row k*band_rows: the shape an all-gather wants), or the listed tiles back
  * to back (tile k at floats [192 k, 192 k + 192): its 64 pixels row by row; slots of a ragged edge tile that
  * lie outside the image are never written).
- * tile_cost (nullable, with a tile list only): one cost estimate per listed tile, as rt_tile_costs reported
- * them for an earlier launch of the same view; the launch is then scheduled longest job first at once
- * instead of measuring the costs itself first.  The arrays are host memory, read during the call.
+ * tile_cost, tile_peak (nullable, with a tile list only): per listed tile, its cost and the cost of its most
+ * expensive pixel as rt_tile_costs reported them for an earlier launch of the same view; the launch is then
+ * scheduled longest job first at once instead of measuring the tiles itself first (tile_peak == NULL: ordered
+ * by tile_cost).  The arrays are host memory, read during the call.
  * The launch is asynchronous on `hip_stream` (a hipStream_t, NULL = default stream). */
 typedef struct rt_tile_spec {
     int32_t band_rows;       /* > 0, multiple of 8 */
@@ -199,6 +200,7 @@ typedef struct rt_tile_spec {
     int32_t compact;
     const uint32_t *tile_list;
     const uint32_t *tile_cost;
+    const uint32_t *tile_peak;
     int32_t num_tiles;
 } rt_tile_spec;
 
@@ -226,10 +228,12 @@ int32_t rt_tile_owned_rows(const rt_tile_spec *tiles, int32_t height);
  * tile spec) adds up, per tile, the work of its pixels (traversal steps, generated rays and shaded hits,
  * weighted); this call waits for that launch and copies the figures out: tile_ids[i] = the tile's index in
  * the image (ty * ceil(width / 8) + tx), costs[i] its cost (opaque units; bit 0 says whether a ray of the tile
- * entered a mesh), for i < *count (= the tiles of that launch, at most `capacity`).  RT_ERR_INVALID if no launch of the current view has collected costs.  The reference
+ * entered a mesh), peaks[i] (nullable) the cost of its most expensive pixel, for i < *count (= the tiles of
+ * that launch, at most `capacity`).  The sum is what balances GPUs (rt_partition_tiles), the peak what orders
+ * a launch: a tile of one frame is a job as long as its longest pixel, and the longest jobs must start first.  RT_ERR_INVALID if no launch of the current view has collected costs.  The reference
  * has no counterpart (one GPU, one thread per pixel, src/dispatch.cu:136-139); this is what lets N GPUs
  * share a frame by cost instead of by area. */
-rt_status rt_tile_costs(rt_ctx *ctx, uint32_t *tile_ids, uint32_t *costs, int32_t capacity, int32_t *count);
+rt_status rt_tile_costs(rt_ctx *ctx, uint32_t *tile_ids, uint32_t *costs, uint32_t *peaks, int32_t capacity, int32_t *count);
 
 /* Ownership of the tiles_x x tiles_y tiles of an image over n_ranks GPUs: owner[ty * tiles_x + tx] = rank.
  * cost == NULL: interleaved, owner = (tx + ty) % n_ranks (what a view's first, cost-collecting launch uses).

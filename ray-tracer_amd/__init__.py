@@ -46,7 +46,8 @@ class rt_render_settings(C.Structure):
 
 class rt_tile_spec(C.Structure):
     _fields_ = [("band_rows", C.c_int32), ("band_first", C.c_int32), ("band_stride", C.c_int32), ("compact", C.c_int32),
-                ("tile_list", C.POINTER(C.c_uint32)), ("tile_cost", C.POINTER(C.c_uint32)), ("num_tiles", C.c_int32)]
+                ("tile_list", C.POINTER(C.c_uint32)), ("tile_cost", C.POINTER(C.c_uint32)), ("tile_peak", C.POINTER(C.c_uint32)),
+                ("num_tiles", C.c_int32)]
 
 
 class rt_rank(C.Structure):
@@ -169,7 +170,7 @@ def lib():
                                          C.POINTER(rt_tile_spec), vp, vp]
     L.rt_tile_owned_rows.argtypes = [C.POINTER(rt_tile_spec), C.c_int32]
     u32p = C.POINTER(C.c_uint32)
-    L.rt_tile_costs.argtypes = [vp, u32p, u32p, C.c_int32, C.POINTER(C.c_int32)]
+    L.rt_tile_costs.argtypes = [vp, u32p, u32p, u32p, C.c_int32, C.POINTER(C.c_int32)]
     L.rt_partition_tiles.argtypes = [u32p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
     L.rt_tiles_copy_device.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, u32p, C.c_int32, C.c_int32, vp]
     L.rt_max_batch_frames.argtypes = [vp, C.c_int32, C.c_int32]
@@ -547,15 +548,15 @@ class Context:
         """waits for this context's most recent launch"""
         self._check(lib().rt_ctx_synchronize(self._h))
 
-    def tile_costs(self):
-        """(tile indices in the image, costs) of the current view's tiles as its first launch measured them
-        (rt_tile_costs; waits for that launch)"""
+    def tile_costs(self, with_peaks=False):
+        """(tile indices in the image, costs[, peak pixel costs]) of the current view's tiles as its first launch measured
+        them (rt_tile_costs; waits for that launch)"""
         n = C.c_int32()
-        self._check(lib().rt_tile_costs(self._h, None, None, 0, C.byref(n)))
-        ids, costs = np.empty(n.value, np.uint32), np.empty(n.value, np.uint32)
+        self._check(lib().rt_tile_costs(self._h, None, None, None, 0, C.byref(n)))
+        ids, costs, peaks = np.empty(n.value, np.uint32), np.empty(n.value, np.uint32), np.empty(n.value, np.uint32)
         u32p = C.POINTER(C.c_uint32)
-        self._check(lib().rt_tile_costs(self._h, ids.ctypes.data_as(u32p), costs.ctypes.data_as(u32p), n.value, C.byref(n)))
-        return ids, costs
+        self._check(lib().rt_tile_costs(self._h, ids.ctypes.data_as(u32p), costs.ctypes.data_as(u32p), peaks.ctypes.data_as(u32p), n.value, C.byref(n)))
+        return (ids, costs, peaks) if with_peaks else (ids, costs)
 
     def max_batch_frames(self, width, height):
         """frames the multi-frame entry points put into one launch for this image size (rt_max_batch_frames)"""
@@ -624,7 +625,7 @@ def render_frames(ctx, scene, camera, render_data, data, times_ms):
     return buf
 
 
-def _tile_spec(band_rows, band_first, band_stride, compact, tile_list, tile_cost):
+def _tile_spec(band_rows, band_first, band_stride, compact, tile_list, tile_cost, tile_peak=None):
     """rt_tile_spec + the arrays it points at (keep the second value alive for the duration of the call)"""
     ts = rt_tile_spec(int(band_rows), int(band_first), int(band_stride), int(bool(compact)))
     keep = None
@@ -640,25 +641,31 @@ def _tile_spec(band_rows, band_first, band_stride, compact, tile_list, tile_cost
             assert cost.size == ids.size
             if cost.size:
                 ts.tile_cost = cost.ctypes.data_as(C.POINTER(C.c_uint32))
-        keep = (ids, backing, cost)
+        peak = None
+        if tile_peak is not None and cost is not None:
+            peak = np.ascontiguousarray(tile_peak, dtype=np.uint32)
+            assert peak.size == ids.size
+            if peak.size:
+                ts.tile_peak = peak.ctypes.data_as(C.POINTER(C.c_uint32))
+        keep = (ids, backing, cost, peak)
     return ts, keep
 
 
 def render_device(ctx, scene, camera, render_data, time_ms, frame_num, d_out, d_prev=None,
-                  band_rows=8, band_first=0, band_stride=1, compact=False, stream=None, tile_list=None, tile_cost=None):
+                  band_rows=8, band_first=0, band_stride=1, compact=False, stream=None, tile_list=None, tile_cost=None, tile_peak=None):
     """Device-buffer form: d_out / d_prev are device pointers (ints, e.g. torch.Tensor.data_ptr()).  tile_list: the
     8x8 tiles to render (indices ty * ceil(W / 8) + tx) instead of bands."""
-    ts, keep = _tile_spec(band_rows, band_first, band_stride, compact, tile_list, tile_cost)
+    ts, keep = _tile_spec(band_rows, band_first, band_stride, compact, tile_list, tile_cost, tile_peak)
     ctx._check(lib().rt_render_device(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), int(time_ms), int(frame_num),
                                       C.byref(ts), C.c_void_p(d_prev or 0), C.c_void_p(d_out), C.c_void_p(stream or 0)))
     del keep
 
 
 def render_device_batch(ctx, scene, camera, render_data, times_ms, frame_num, d_frame,
-                        band_rows=8, band_first=0, band_stride=1, compact=False, stream=None, tile_list=None, tile_cost=None):
+                        band_rows=8, band_first=0, band_stride=1, compact=False, stream=None, tile_list=None, tile_cost=None, tile_peak=None):
     """len(times_ms) consecutive progressive frames in ONE launch, accumulated in place in the device
     buffer d_frame (bit-identical to that many render_device calls; see rt_render_device_batch)."""
-    ts, keep = _tile_spec(band_rows, band_first, band_stride, compact, tile_list, tile_cost)
+    ts, keep = _tile_spec(band_rows, band_first, band_stride, compact, tile_list, tile_cost, tile_peak)
     t = (C.c_int32 * len(times_ms))(*[int(x) for x in times_ms])
     ctx._check(lib().rt_render_device_batch(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), t, len(times_ms), int(frame_num),
                                             C.byref(ts), C.c_void_p(d_frame), C.c_void_p(stream or 0)))

@@ -55,7 +55,7 @@ struct Stage {
 struct MultiState {
     std::vector<uint32_t> key;           /* camera, image size, number of ranks, scene ids */
     int stage = 0;                       /* 0 nothing; 1 the interleaved lists are in use and a call has collected costs; 2 balanced */
-    std::vector<std::vector<uint32_t>> lists, costs;      /* per rank: its tiles (image indices) and their measured costs */
+    std::vector<std::vector<uint32_t>> lists, costs, peaks;   /* per rank: its tiles (image indices), their measured costs and peak pixel costs */
 };
 
 }  // namespace
@@ -94,8 +94,11 @@ struct rt_ctx {
     size_t tile_order_cap = 0;
     uint32_t *d_tile_cost = nullptr;     /* per tile: the weighted work of its pixels, collected by the first launch of a view */
     size_t tile_cost_cap = 0;
+    uint32_t *d_tile_peak = nullptr;     /* ... and of its most expensive pixel */
+    size_t tile_peak_cap = 0;
     int cost_state = 0;                  /* 0 nothing, 1 a launch of this view collected costs, 2 cost_host holds them (and the order is refined) */
     std::vector<uint32_t> cost_host;     /* the measured (or caller-supplied) costs, per local tile */
+    std::vector<uint32_t> peak_host;     /* ... and peak pixel costs: what the schedule sorts by */
     int order_num_heavy = 0;             /* refined order: how many leading tiles go first for ALL frames of a multi-frame launch */
     float *d_partial = nullptr;          /* multi-frame launches: one plane of per-pixel frame means per frame */
     size_t partial_cap = 0;              /* floats */
@@ -274,6 +277,7 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->d_tile_order) (void)hipFree(ctx->d_tile_order);
     if (ctx->d_tile_cost) (void)hipFree(ctx->d_tile_cost);
+    if (ctx->d_tile_peak) (void)hipFree(ctx->d_tile_peak);
     if (ctx->d_job_order) (void)hipFree(ctx->d_job_order);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
     if (ctx->d_bands) (void)hipFree(ctx->d_bands);
@@ -478,14 +482,16 @@ static int launch_blocks(const rt_ctx *ctx, const rt_scene *scene, int num_tiles
 /* the schedule of a multi-frame launch (see its use in render_frames): `order` is the launch's tile order
  * (any permutation of 0..n-1; ties in cost keep it), cost[t] the measured cost of tile t - bit 0 set if a ray of the
  * tile entered a mesh: those are the long jobs; the others (sky, ground) follow frame by frame */
-static void build_job_order(const std::vector<uint32_t> &order, const std::vector<uint32_t> &cost, uint32_t top_max, uint32_t frames,
-                            std::vector<uint32_t> &jobs)
+static void build_job_order(const std::vector<uint32_t> &order, const std::vector<uint32_t> &cost, const std::vector<uint32_t> &peak, uint32_t top_max,
+                            uint32_t frames, std::vector<uint32_t> &jobs)
 {
     const uint32_t n = (uint32_t)order.size();
     std::vector<uint32_t> idx;
     idx.reserve(n);
     for (uint32_t t : order) if (cost[t] & 1u) idx.push_back(t);
-    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+    /* a job lasts as long as its longest pixel: by decreasing peak pixel cost (measured at N = 8, 1024 spp: ordering by
+     * the tile's SUM left a rank in four with a long pixel started late - ranks 611-718 ms; by peak 612-631) */
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return peak[x] > peak[y]; });
     const uint32_t top = top_max < (uint32_t)idx.size() ? top_max : (uint32_t)idx.size();
     jobs.clear();
     jobs.reserve((size_t)n * frames);
@@ -520,17 +526,19 @@ rt_status read_costs_and_refine(rt_ctx *ctx, hipStream_t stream)
     if (ctx->cost_state == 1) {
         /* on the launch stream: the launch that collected the costs ran on it (or this stream has been ordered
          * behind it), and a blocking copy on the null stream would not wait for a non-blocking stream's kernel */
-        std::vector<uint32_t> cost(n);
+        std::vector<uint32_t> cost(n), peak(n);
         RT_HIP(ctx, hipMemcpyAsync(cost.data(), ctx->d_tile_cost, (size_t)n * 4, hipMemcpyDeviceToHost, stream), "reading tile costs");
+        RT_HIP(ctx, hipMemcpyAsync(peak.data(), ctx->d_tile_peak, (size_t)n * 4, hipMemcpyDeviceToHost, stream), "reading tile costs");
         RT_HIP(ctx, hipStreamSynchronize(stream), "reading tile costs");
         ctx->cost_host.swap(cost);
+        ctx->peak_host.swap(peak);
     }
     if (ctx->use_order && ctx->heavy_top > 0) {
-        const std::vector<uint32_t> &cost = ctx->cost_host;
+        const std::vector<uint32_t> &cost = ctx->cost_host, &peak = ctx->peak_host;
         std::vector<uint32_t> idx;
         idx.reserve(n);
         for (uint32_t t : ctx->order_host) if (cost[t] & 1u) idx.push_back(t);          /* tiles with a ray in a mesh */
-        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return peak[x] > peak[y]; });
         const uint32_t top = (uint32_t)ctx->heavy_top < (uint32_t)idx.size() ? (uint32_t)ctx->heavy_top : (uint32_t)idx.size();
         std::vector<char> taken(n, 0);
         std::vector<uint32_t> merged;
@@ -572,7 +580,7 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
     if (listed) {
         if (t->num_tiles < 0 || t->num_tiles > tiles_x * tiles_y) return set_err(ctx, RT_ERR_INVALID, "bad tile spec (num_tiles)");
     } else {
-        if (t->tile_cost) return set_err(ctx, RT_ERR_INVALID, "bad tile spec (tile_cost needs a tile_list)");
+        if (t->tile_cost || t->tile_peak) return set_err(ctx, RT_ERR_INVALID, "bad tile spec (tile_cost / tile_peak need a tile_list)");
         if (t->band_rows <= 0 || (t->band_rows & 7) || t->band_stride <= 0 || t->band_first < 0 || t->band_first >= t->band_stride)
             return set_err(ctx, RT_ERR_INVALID, "bad tile spec (band_rows must be a positive multiple of 8, 0 <= band_first < band_stride)");
     }
@@ -616,6 +624,7 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
         if (listed) {
             uint64_t h = fnv1a(t->tile_list, (size_t)n * 4);
             if (t->tile_cost) h = fnv1a(t->tile_cost, (size_t)n * 4, h);
+            if (t->tile_cost && t->tile_peak) h = fnv1a(t->tile_peak, (size_t)n * 4, h);
             key.push_back(0xffffffffu); key.push_back(n); key.push_back((uint32_t)h); key.push_back((uint32_t)(h >> 32)); key.push_back(t->tile_cost ? 1u : 0u);
         } else {
             key.push_back((uint32_t)a.band_rows); key.push_back((uint32_t)a.band_first); key.push_back((uint32_t)a.band_stride);
@@ -643,10 +652,12 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
             ctx->tiles_host.swap(th);
             ctx->cost_state = 0;
             ctx->cost_host.clear();
+            ctx->peak_host.clear();
             ctx->order_num_heavy = 0;
             ctx->job_frames = 0;
             rt_status st;
             if ((st = grow_u32(ctx, &ctx->d_tile_cost, &ctx->tile_cost_cap, n, "allocating tile costs")) != RT_OK) return st;
+            if ((st = grow_u32(ctx, &ctx->d_tile_peak, &ctx->tile_peak_cap, n, "allocating tile costs")) != RT_OK) return st;
             ctx->use_order = ctx->heavy_first && scene->flat.num_meshes > 0 && n > 1;
             if (ctx->use_order) {
                 /* longest-job-first, first guess: tiles whose centre ray enters a mesh root box are handed out
@@ -690,6 +701,8 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
             if (listed && t->tile_cost) {
                 /* the caller knows what the tiles cost (an earlier launch of the view, possibly on other GPUs) */
                 ctx->cost_host.assign(t->tile_cost, t->tile_cost + n);
+                if (t->tile_peak) ctx->peak_host.assign(t->tile_peak, t->tile_peak + n);
+                else ctx->peak_host = ctx->cost_host;
                 if ((st = read_costs_and_refine(ctx, stream)) != RT_OK) return st;
             }
             ctx->order_key = key;
@@ -704,7 +717,9 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
          * (see px_fetch): with the true costs that is worth 10 % at three frames per launch (with the guess, nothing). */
         if (ctx->cost_state == 0) {
             RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)n * 4, stream), "clearing tile costs");
+            RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_peak, 0, (size_t)n * 4, stream), "clearing tile costs");
             a.tile_cost = ctx->d_tile_cost;
+            a.tile_peak = ctx->d_tile_peak;
             collecting = true;
         } else if (ctx->cost_state == 1 && ctx->use_order) {
             rt_status st = read_costs_and_refine(ctx, stream);
@@ -723,10 +738,10 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
              * schedule renders the same image.  (Measured, 20 frames of the monkey configuration: +6 % on one
              * GPU and +25 % on the share one of 8 GPUs renders, against "the 1,024 most expensive tiles of frame
              * 0, of frame 1, ... first".) */
-            if (ctx->lpt && ctx->cost_state == 2 && n_frames > 1 && n <= (RT_JOB_TILE_MASK + 1u) && ctx->cost_host.size() == n) {
+            if (ctx->lpt && ctx->cost_state == 2 && n_frames > 1 && n <= (RT_JOB_TILE_MASK + 1u) && ctx->cost_host.size() == n && ctx->peak_host.size() == n) {
                 if (ctx->job_frames != n_frames) {
                     std::vector<uint32_t> jobs;
-                    build_job_order(ctx->order_host, ctx->cost_host, (uint32_t)ctx->lpt_top, (uint32_t)n_frames, jobs);
+                    build_job_order(ctx->order_host, ctx->cost_host, ctx->peak_host, (uint32_t)ctx->lpt_top, (uint32_t)n_frames, jobs);
                     rt_status st = grow_u32(ctx, &ctx->d_job_order, &ctx->job_cap, jobs.size(), "allocating the launch schedule");
                     if (st != RT_OK) return st;
                     RT_HIP(ctx, hipMemcpyAsync(ctx->d_job_order, jobs.data(), jobs.size() * 4, hipMemcpyHostToDevice, stream), "uploading the launch schedule");
@@ -825,7 +840,7 @@ extern "C" rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, 
     return render_frames(ctx, scene, cam, rs, times_ms, n_frames, frame_num, tiles, nullptr, d_frame, hip_stream, true);
 }
 
-extern "C" rt_status rt_tile_costs(rt_ctx *ctx, uint32_t *tile_ids, uint32_t *costs, int32_t capacity, int32_t *count)
+extern "C" rt_status rt_tile_costs(rt_ctx *ctx, uint32_t *tile_ids, uint32_t *costs, uint32_t *peaks, int32_t capacity, int32_t *count)
 {
     if (!ctx || !count || capacity < 0 || (capacity > 0 && (!tile_ids || !costs))) return set_err(ctx, RT_ERR_INVALID, "null argument");
     *count = 0;
@@ -836,9 +851,9 @@ extern "C" rt_status rt_tile_costs(rt_ctx *ctx, uint32_t *tile_ids, uint32_t *co
         if (st != RT_OK) return st;
     }
     const size_t n = ctx->tiles_host.size();
-    if (ctx->cost_host.size() != n) return set_err(ctx, RT_ERR_INVALID, "no launch of the current view has collected tile costs");
+    if (ctx->cost_host.size() != n || ctx->peak_host.size() != n) return set_err(ctx, RT_ERR_INVALID, "no launch of the current view has collected tile costs");
     const size_t m = n < (size_t)capacity ? n : (size_t)capacity;
-    for (size_t i = 0; i < m; i++) { tile_ids[i] = ctx->tiles_host[i]; costs[i] = ctx->cost_host[i]; }
+    for (size_t i = 0; i < m; i++) { tile_ids[i] = ctx->tiles_host[i]; costs[i] = ctx->cost_host[i]; if (peaks) peaks[i] = ctx->peak_host[i]; }
     *count = (int32_t)n;
     return RT_OK;
 }
@@ -1200,6 +1215,7 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
             if ((st = rt_partition_tiles(nullptr, tiles_x, tiles_y, n_ranks, owner.data())) != RT_OK) return set_err(root, st, "cannot partition the image");
             ms.lists.assign((size_t)n_ranks, std::vector<uint32_t>());
             ms.costs.assign((size_t)n_ranks, std::vector<uint32_t>());
+            ms.peaks.assign((size_t)n_ranks, std::vector<uint32_t>());
             for (size_t g = 0; g < owner.size(); g++) ms.lists[(size_t)owner[g]].push_back((uint32_t)g);
             ms.key = key;
             ms.stage = 0;
@@ -1207,17 +1223,17 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
             /* the previous call measured the tiles: collect every rank's figures (this waits for those launches, which
              * the caller has normally consumed already), then deal the tiles out again by cost.  All read-backs happen
              * here, before any rank is launched, so no rank's launch waits on another rank's kernel. */
-            std::vector<uint32_t> cost((size_t)tiles_x * tiles_y, 0u);
+            std::vector<uint32_t> cost((size_t)tiles_x * tiles_y, 0u), peak((size_t)tiles_x * tiles_y, 0u);
             bool have_all = true;
             for (int i = 0; i < n_ranks && have_all; i++) {
                 const size_t cnt = ms.lists[(size_t)i].size();
                 if (cnt == 0) continue;
-                std::vector<uint32_t> ids(cnt), cs(cnt);
+                std::vector<uint32_t> ids(cnt), cs(cnt), ps(cnt);
                 int32_t got = 0;
-                if (rt_tile_costs(ranks[i].ctx, ids.data(), cs.data(), (int32_t)cnt, &got) != RT_OK || (size_t)got != cnt) { have_all = false; break; }
+                if (rt_tile_costs(ranks[i].ctx, ids.data(), cs.data(), ps.data(), (int32_t)cnt, &got) != RT_OK || (size_t)got != cnt) { have_all = false; break; }
                 for (size_t k = 0; k < cnt && have_all; k++) {
                     if (ids[k] != ms.lists[(size_t)i][k]) have_all = false;     /* the rank's context has rendered another view since */
-                    else cost[ids[k]] = cs[k];
+                    else { cost[ids[k]] = cs[k]; peak[ids[k]] = ps[k]; }
                 }
             }
             RT_HIP(root, hipSetDevice(root->device), "selecting device");
@@ -1225,7 +1241,10 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
                 if ((st = rt_partition_tiles(cost.data(), tiles_x, tiles_y, n_ranks, owner.data())) != RT_OK) return set_err(root, st, "cannot partition the image");
                 ms.lists.assign((size_t)n_ranks, std::vector<uint32_t>());
                 ms.costs.assign((size_t)n_ranks, std::vector<uint32_t>());
-                for (size_t g = 0; g < owner.size(); g++) { ms.lists[(size_t)owner[g]].push_back((uint32_t)g); ms.costs[(size_t)owner[g]].push_back(cost[g]); }
+                ms.peaks.assign((size_t)n_ranks, std::vector<uint32_t>());
+                for (size_t g = 0; g < owner.size(); g++) {
+                    ms.lists[(size_t)owner[g]].push_back((uint32_t)g); ms.costs[(size_t)owner[g]].push_back(cost[g]); ms.peaks[(size_t)owner[g]].push_back(peak[g]);
+                }
                 ms.stage = 2;
             } else {
                 ms.stage = 0;            /* (a rank's view was replaced in between: measure again) */
@@ -1239,6 +1258,7 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
             p.spec.tile_list = ms.lists[(size_t)i].data();
             p.spec.num_tiles = (int32_t)ms.lists[(size_t)i].size();
             p.spec.tile_cost = (ms.stage == 2 && p.spec.num_tiles > 0) ? ms.costs[(size_t)i].data() : nullptr;
+            p.spec.tile_peak = (ms.stage == 2 && p.spec.num_tiles > 0) ? ms.peaks[(size_t)i].data() : nullptr;
             /* (an empty vector's data() may be null, which would read as "no list") */
             static const uint32_t none = 0;
             if (!p.spec.tile_list) p.spec.tile_list = &none;

@@ -165,7 +165,9 @@ typedef struct {
     const float *prev;             /* full frame or NULL */
     float *out;
     uint32_t *tile_counter;        /* zeroed before the launch */
-    uint32_t *tile_cost;           /* or NULL: per tile, the traversal macro steps its pixels took (all frames of the launch) */
+    uint32_t *tile_cost;           /* or NULL: per tile, what its pixels cost (RT_COST_* units, all frames of the launch) << 1, bit 0: a
+                                      ray of the tile entered a mesh */
+    uint32_t *tile_peak;           /* with tile_cost: per tile, the cost of its most expensive pixel (of any one frame) */
     unsigned long long *stats;     /* development builds only (-DRT_STATS): section counters */
 } rt_kernel_args;
 

@@ -233,7 +233,11 @@ __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, 
     if (a.tile_cost) {
         /* cost units in bits 31..1 of the tile's sum; bit 0: some pixel of the tile traversed a mesh (those tiles are
          * the long jobs the schedule puts first, rt_capi.cpp build_job_order) */
-        atomicAdd(a.tile_cost + tile, ((p.frame_steps & 0x7fffffffu) >> RT_FRAME_BITS) << 1);
+        const unsigned units = (p.frame_steps & 0x7fffffffu) >> RT_FRAME_BITS;
+        atomicAdd(a.tile_cost + tile, units << 1);
+        /* ... and the tile's most expensive pixel: a tile-frame is one job, as long as its longest pixel (a pixel's samples
+         * are one sequential stream), and the schedule starts the longest jobs first */
+        atomicMax(a.tile_peak + tile, units);
         if (p.frame_steps >> 31) atomicOr(a.tile_cost + tile, 1u);
     }
     p.mode = M_FETCH;

@@ -9,7 +9,7 @@ when the process group's backend is "nccl").  Two ways of cutting the image:
   bands b with b % world == r into a compact buffer; de-interleaving is one permute + reshape;
 * tile lists (round 3, what bench.py uses for N > 1): every rank owns a list of 8x8 tiles.  The
   view's first launch runs on an interleaved ownership and measures what every tile costs; the
-  costs are summed over the ranks (one small all-reduce, the only other collective), every rank
+  costs and peak pixel costs are merged over the ranks (one small all-reduce, the only other collective), every rank
   computes the same longest-processing-time-first ownership from them (``rt_partition_tiles``) and
   from then on the ranks finish together.  A rank's compact image is its tiles back to back; rank 0
   puts each gathered image into the frame with ``rt_tiles_copy_device``.
@@ -100,24 +100,26 @@ def initial_ownership(width, height, world):
 
 
 def balanced_ownership(ctx, width, height, lists, rank, world, device=None, group=None):
-    """After this rank's context has rendered its tiles of the interleaved ownership once: sums every rank's
-    measured tile costs (one all-reduce of a [tiles] int64 tensor: 260 KB at 1920x1080) and returns
-    (owner, cost) - the same on every rank.  cost[tile] is the summed figure, owner the
-    longest-processing-time-first ownership computed from it."""
+    """After this rank's context has rendered its tiles of the interleaved ownership once: combines every rank's
+    measured tile figures (one all-reduce of a [2, tiles] int64 tensor: 520 KB at 1920x1080; every tile was measured by
+    exactly one rank, so the sum is a merge) and returns (owner, cost, peak) - the same on every rank.  cost[tile] is what
+    the tile's pixels cost, owner the longest-processing-time-first ownership computed from it; peak[tile] is the cost of
+    the tile's most expensive pixel, which is what a launch orders its jobs by."""
     rt = _rt()
     tx, ty = tiles_xy(width, height)
-    cost = np.zeros(tx * ty, np.int64)
-    ids, c = ctx.tile_costs()
+    both = np.zeros((2, tx * ty), np.int64)
+    ids, c, pk = ctx.tile_costs(with_peaks=True)
     assert np.array_equal(ids, lists[rank]), "the context's current view is not this rank's tile list"
-    cost[ids] = c
+    both[0, ids] = c
+    both[1, ids] = pk
     if world > 1:
-        t = torch.from_numpy(cost)
+        t = torch.from_numpy(both)
         if dist.get_backend(group) != "gloo":
             t = t.to(device)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        cost = t.cpu().numpy()
-    cost = np.minimum(cost, 0xffffffff).astype(np.uint32)
-    return rt.partition_tiles(width, height, world, cost), cost
+        both = t.cpu().numpy()
+    both = np.minimum(both, 0xffffffff).astype(np.uint32)
+    return rt.partition_tiles(width, height, world, both[0]), both[0], both[1]
 
 
 def scatter_tiles(frame, compact, tile_ids, width, height, ctx=None, stream=None):

@@ -56,7 +56,8 @@ for seed in range(first, first + count):
             buf = torch.zeros((max(len(ids), 1) * 192,), device="cuda:0")
             bufs.append(buf)
             hints = rng.integers(0, 1000, len(ids)).astype(np.uint32) if r % 2 else None
-            rt.render_device_batch(ctxs[r], scenes[r], cam, rd, times, 0, buf.data_ptr(), compact=True, stream=stream, tile_list=ids, tile_cost=hints)
+            peaks = rng.integers(0, 100, len(ids)).astype(np.uint32) if r % 4 == 1 else None
+            rt.render_device_batch(ctxs[r], scenes[r], cam, rd, times, 0, buf.data_ptr(), compact=True, stream=stream, tile_list=ids, tile_cost=hints, tile_peak=peaks)
             rt.gather(ctxs[0], out.data_ptr(), W, H, ctxs[r], buf.data_ptr(), stream=stream, tile_list=ids)
     else:
         for r in range(n):

@@ -33,7 +33,7 @@ def test_struct_layouts(rt):
     assert ctypes.sizeof(rt.rt_material) == 4 * (2 + 3 + 3 + 3 + 1 + 1 + 1 + 3 + 1) + 8 + 8      # ... + img_w, img_h + pointer
     assert ctypes.sizeof(rt.rt_camera) == 4 * 14
     assert ctypes.sizeof(rt.rt_render_settings) == 4 * 6
-    assert ctypes.sizeof(rt.rt_tile_spec) == 40       # four ints, two pointers, one int (+ padding)
+    assert ctypes.sizeof(rt.rt_tile_spec) == 48       # four ints, three pointers, one int (+ padding)
 
 
 def test_material_factories(rt):

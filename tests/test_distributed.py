@@ -65,9 +65,10 @@ class _CostsFromPixels:
     def __init__(self, ids, compact):
         self.ids, self.compact = ids, compact
 
-    def tile_costs(self):
+    def tile_costs(self, with_peaks=False):
         c = self.compact[:len(self.ids) * 192].reshape(len(self.ids), 192)
-        return self.ids, (np.abs(np.nan_to_num(c)).sum(axis=1) * 100).astype(np.uint32) + 1
+        cost = (np.abs(np.nan_to_num(c)).sum(axis=1) * 100).astype(np.uint32) + 1
+        return (self.ids, cost, (np.abs(np.nan_to_num(c)).max(axis=1) * 100).astype(np.uint32)) if with_peaks else (self.ids, cost)
 
 
 def _tile_worker(rank, world, port, W, H, spp, result_path):
@@ -95,7 +96,8 @@ def _tile_worker(rank, world, port, W, H, spp, result_path):
 
         # pass 1: interleaved ownership; "measure"; pass 2: cost-balanced ownership, the same on both ranks
         lists = dm.tile_lists(dm.initial_ownership(W, H, world), world)
-        owner, cost = dm.balanced_ownership(_CostsFromPixels(lists[rank], my_image(lists)), W, H, lists, rank, world)
+        owner, cost, peak = dm.balanced_ownership(_CostsFromPixels(lists[rank], my_image(lists)), W, H, lists, rank, world)
+        assert peak.shape == cost.shape and (peak.astype(np.int64) <= cost.astype(np.int64)).all()
         lists2 = dm.tile_lists(owner, world)
         loads = [int(cost[l].sum()) for l in lists2]
         assert max(loads) - min(loads) <= int(cost.max()), loads          # LPT: within one job of each other

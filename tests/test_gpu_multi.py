@@ -153,8 +153,8 @@ def test_tile_list_forms(rt, orc, models_dir, W, H):
     rt.render_device(ctx, scene, cam, rd, times[0], 0, a.data_ptr(), stream=st, tile_list=ids)
     torch.cuda.synchronize()
     assert torch.equal(a[mask].view(torch.int32), whole[mask].view(torch.int32)) and bool((a[~mask] == -1.0).all())
-    tile_ids, cost = ctx.tile_costs()
-    assert np.array_equal(tile_ids, ids) and cost.min() > 0
+    tile_ids, cost, peak = ctx.tile_costs(with_peaks=True)
+    assert np.array_equal(tile_ids, ids) and cost.min() > 0 and peak.min() > 0 and (2 * peak.astype(np.int64) <= cost.astype(np.int64) + 1).all()
     # (b) compact + the two ways back into a frame
     c = torch.full((len(ids) * 192,), -2.0, device="cuda:0")
     rt.render_device(ctx, scene, cam, rd, times[0], 0, c.data_ptr(), compact=True, stream=st, tile_list=ids)
@@ -167,13 +167,13 @@ def test_tile_list_forms(rt, orc, models_dir, W, H):
         torch.cuda.synchronize()
         assert torch.equal(b.view(torch.int32), a.view(torch.int32)), how
     # (c) three progressive frames in one launch, in place
-    for hints in (None, cost):
+    for hints, peaks in ((None, None), (cost, None), (cost, peak)):
         c3 = torch.zeros((len(ids) * 192,), device="cuda:0")
-        rt.render_device_batch(ctx, scene, cam, rd, times, 0, c3.data_ptr(), compact=True, stream=st, tile_list=ids, tile_cost=hints)
+        rt.render_device_batch(ctx, scene, cam, rd, times, 0, c3.data_ptr(), compact=True, stream=st, tile_list=ids, tile_cost=hints, tile_peak=peaks)
         b = torch.full((H, W, 3), -1.0, device="cuda:0")
         rt.tiles_copy_device(ctx, c3.data_ptr(), b.data_ptr(), W, H, ids, True, st)
         f3 = torch.full((H, W, 3), -1.0, device="cuda:0")
-        rt.render_device_batch(ctx, scene, cam, rd, times, 0, f3.data_ptr(), stream=st, tile_list=ids, tile_cost=hints)
+        rt.render_device_batch(ctx, scene, cam, rd, times, 0, f3.data_ptr(), stream=st, tile_list=ids, tile_cost=hints, tile_peak=peaks)
         torch.cuda.synchronize()
         for got in (b, f3):
             assert torch.equal(got[mask].view(torch.int32), whole3[mask].view(torch.int32)) and bool((got[~mask] == -1.0).all())

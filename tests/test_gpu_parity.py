@@ -188,8 +188,8 @@ def test_full_size_properties(rt, orc, ctx, models_dir, name):
     stream = torch.cuda.current_stream().cuda_stream
     full = torch.empty((H, W, 3), device="cuda:0")
     rt.render_device(ctx, scene, cam, rd, 12345, 0, full.data_ptr(), stream=stream)
-    ids, cost = ctx.tile_costs()             # the launch above was the first of its view: it measured the tiles
-    assert np.array_equal(ids, np.arange(240 * 135, dtype=np.uint32)) and cost.min() > 0
+    ids, cost, peak = ctx.tile_costs(with_peaks=True)        # the launch above was the first of its view: it measured the tiles
+    assert np.array_equal(ids, np.arange(240 * 135, dtype=np.uint32)) and cost.min() > 0 and peak.min() > 0
     world = 8
     stacked = torch.zeros((world, dist_mod.max_owned_rows(H, 8, world), W, 3), device="cuda:0")
     for r in range(world):
@@ -206,8 +206,8 @@ def test_full_size_properties(rt, orc, ctx, models_dir, name):
         rt.render_device(ctx, scene, cam, rd, times[i], i, y.data_ptr(), d_prev=x.data_ptr(), stream=stream)
         x, y = y, x
     # ... and as 8 cost-balanced tile lists, one multi-frame launch each
-    full_cost = np.zeros(240 * 135, np.uint32)
-    full_cost[ids] = cost
+    full_cost, full_peak = np.zeros(240 * 135, np.uint32), np.zeros(240 * 135, np.uint32)
+    full_cost[ids], full_peak[ids] = cost, peak
     owner = rt.partition_tiles(W, H, world, full_cost)
     lists = dist_mod.tile_lists(owner, world)
     loads = np.array([full_cost[l].astype(np.int64).sum() for l in lists])
@@ -215,7 +215,7 @@ def test_full_size_properties(rt, orc, ctx, models_dir, name):
     out = torch.full((H, W, 3), -1.0, device="cuda:0")
     buf = torch.zeros(dist_mod.compact_floats(lists), device="cuda:0")
     for r in range(world):
-        rt.render_device_batch(ctx, scene, cam, rd, times, 0, buf.data_ptr(), compact=True, stream=stream, tile_list=lists[r], tile_cost=full_cost[lists[r]])
+        rt.render_device_batch(ctx, scene, cam, rd, times, 0, buf.data_ptr(), compact=True, stream=stream, tile_list=lists[r], tile_cost=full_cost[lists[r]], tile_peak=full_peak[lists[r]])
         rt.tiles_copy_device(ctx, buf.data_ptr(), out.data_ptr(), W, H, lists[r], True, stream)
     torch.cuda.synchronize()
     assert torch.equal(out.view(torch.int32), x.view(torch.int32))

@@ -8,6 +8,8 @@ per rank, as bench.py does) and prints every rank's kernel time; the slowest is 
     RT_PROBE_PART=lists   cost-balanced tile lists (bench.py's default; the warm-up runs on the interleaved ownership and
                           measures the tiles) | bands (round 2: band b of 8 rows -> rank b % N) | both
     RT_PROBE_DUMP=path    also writes {N: {part: {"ms": [...], "lists": [[tile ids]...]}}} as JSON (tools/fit_cost_weights.py)
+    RT_PROBE_LISTS=path   lists only: take the ownership from an earlier dump instead of computing it (the tiles are still
+                          measured first, for the hints): same partition, different builds' schedules
 """
 import importlib, json, os, sys
 import numpy as np
@@ -36,22 +38,24 @@ for n in [int(x) for x in os.environ.get("RT_PROBE_N", "1,2,4,8").split(",")]:
         if part == "lists":
             # phase 1: every rank renders its interleaved share once and measures its tiles; the figures are summed
             lists0 = dm.tile_lists(dm.initial_ownership(W, H, n), n)
-            cost = np.zeros(tiles_x * tiles_y, np.uint32)
+            cost, peak = np.zeros(tiles_x * tiles_y, np.uint32), np.zeros(tiles_x * tiles_y, np.uint32)
             for r in range(n):
                 ctx = rt.Context(0)                      # a rank is a process with its own context: its own view state
                 scene = ctx.commit(so)
                 buf = torch.zeros(dm.compact_floats(lists0), device="cuda:0")
                 rt.render_device_batch(ctx, scene, cam, rd, warm, 0, buf.data_ptr(), compact=True, stream=st, tile_list=lists0[r])
-                ids, c = ctx.tile_costs()
-                cost[ids] = c
+                ids, c, pk = ctx.tile_costs(with_peaks=True)
+                cost[ids], peak[ids] = c, pk
                 del scene, ctx
             lists = dm.tile_lists(rt.partition_tiles(W, H, n, cost), n)
+            if os.environ.get("RT_PROBE_LISTS"):
+                lists = [np.asarray(l, np.uint32) for l in json.load(open(os.environ["RT_PROBE_LISTS"]))["runs"][str(n)]["lists"]["lists"]]
         for r in range(n):
             ctx = rt.Context(0)
             scene = ctx.commit(so)
             if part == "lists":
                 buf = torch.zeros(dm.compact_floats(lists), device="cuda:0")
-                rt.render_device_batch(ctx, scene, cam, rd, timed, 0, buf.data_ptr(), compact=True, stream=st, tile_list=lists[r], tile_cost=cost[lists[r]])
+                rt.render_device_batch(ctx, scene, cam, rd, timed, 0, buf.data_ptr(), compact=True, stream=st, tile_list=lists[r], tile_cost=cost[lists[r]], tile_peak=peak[lists[r]])
             else:
                 buf = torch.zeros((dm.max_owned_rows(H, 8, n), W, 3), device="cuda:0")
                 # warm-up launch of 5 frames (collects tile costs, like bench.py --warmup 5), then the timed launch
