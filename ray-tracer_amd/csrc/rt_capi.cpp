@@ -112,6 +112,8 @@ struct rt_ctx {
     int heavy_top = 1024;                /* RT_AMD_HEAVY_TOP: the refined order moves that many tiles at most to the front (0 = never refine) */
     int lpt = 1;                         /* RT_AMD_LPT=0: the round-1 ticket order (heavy tiles of frame 0, 1, ... first) */
     int lpt_top = 1 << 30;               /* RT_AMD_LPT_TOP: at most this many tiles (most expensive first) are scheduled by cost */
+    int lpt_by_peak = 1, top_by_peak = 0; /* RT_AMD_LPT_BY_PEAK: the multi-frame schedule sorts by the tile's peak pixel cost (0: by its summed cost); RT_AMD_TOP_BY_PEAK: so does the
+                                          * one-frame order (default 0: by the sum - same-box A/B, one 1080p frame: monkey 509 vs 526 ms, cube 171 vs 178, reference scene 0 3,104 vs 3,083) */
     int heavy_first = 1;                 /* RT_AMD_HEAVY_FIRST=0 disables */
     int work_threshold = RT_DEF_WORK_THRESHOLD;      /* lanes; RT_AMD_WORK_THRESHOLD */
     int descend_keep = RT_DEF_DESCEND_KEEP;       /* RT_AMD_DESCEND_KEEP (0..64): 0 = run every descent to its end */
@@ -254,6 +256,8 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (const char *e = getenv("RT_AMD_HEAVY_TOP")) { int v = atoi(e); if (v >= 0) ctx->heavy_top = v; }
     if (const char *e = getenv("RT_AMD_LPT")) ctx->lpt = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_LPT_TOP")) { int v = atoi(e); if (v >= 0) ctx->lpt_top = v; }
+    if (const char *e = getenv("RT_AMD_LPT_BY_PEAK")) ctx->lpt_by_peak = atoi(e) != 0;
+    if (const char *e = getenv("RT_AMD_TOP_BY_PEAK")) ctx->top_by_peak = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_HIT_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->hit_break = v; }
     if (const char *e = getenv("RT_AMD_HIT_LOW")) { int v = atoi(e); if (v >= 0 && v <= 65) ctx->hit_low = v; }
     if (const char *e = getenv("RT_AMD_MIX_BREAK")) { int v = atoi(e); if (v >= 0 && v <= 130) ctx->mix_break = v; }
@@ -538,7 +542,8 @@ rt_status read_costs_and_refine(rt_ctx *ctx, hipStream_t stream)
         std::vector<uint32_t> idx;
         idx.reserve(n);
         for (uint32_t t : ctx->order_host) if (cost[t] & 1u) idx.push_back(t);          /* tiles with a ray in a mesh */
-        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return peak[x] > peak[y]; });
+        const std::vector<uint32_t> &key = ctx->top_by_peak ? peak : cost;
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return key[x] > key[y]; });
         const uint32_t top = (uint32_t)ctx->heavy_top < (uint32_t)idx.size() ? (uint32_t)ctx->heavy_top : (uint32_t)idx.size();
         std::vector<char> taken(n, 0);
         std::vector<uint32_t> merged;
@@ -741,7 +746,7 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
             if (ctx->lpt && ctx->cost_state == 2 && n_frames > 1 && n <= (RT_JOB_TILE_MASK + 1u) && ctx->cost_host.size() == n && ctx->peak_host.size() == n) {
                 if (ctx->job_frames != n_frames) {
                     std::vector<uint32_t> jobs;
-                    build_job_order(ctx->order_host, ctx->cost_host, ctx->peak_host, (uint32_t)ctx->lpt_top, (uint32_t)n_frames, jobs);
+                    build_job_order(ctx->order_host, ctx->cost_host, ctx->lpt_by_peak ? ctx->peak_host : ctx->cost_host, (uint32_t)ctx->lpt_top, (uint32_t)n_frames, jobs);
                     rt_status st = grow_u32(ctx, &ctx->d_job_order, &ctx->job_cap, jobs.size(), "allocating the launch schedule");
                     if (st != RT_OK) return st;
                     RT_HIP(ctx, hipMemcpyAsync(ctx->d_job_order, jobs.data(), jobs.size() * 4, hipMemcpyHostToDevice, stream), "uploading the launch schedule");
