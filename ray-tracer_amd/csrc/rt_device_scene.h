@@ -39,7 +39,9 @@
 #define RT_STACK_ENTRIES RT_BVH_DEPTH /* at most one pending sibling per level below the root */
 #define RT_FRAME_BITS 5               /* a pixel keeps the index of its frame within the launch in this many bits */
 #define RT_MAX_BATCH_FRAMES (1 << RT_FRAME_BITS)   /* frames one launch can render */
+#ifndef RT_SMALL_WG_WAVES
 #define RT_SMALL_WG_WAVES 5            /* workgroups of fewer than 1024 threads are compiled for this many waves per SIMD (<= 96 VGPRs) */
+#endif
 /* Defaults of the render kernel's scheduling thresholds (lanes of a wave; see rt_kernel.hip; RT_AMD_* overrides them).
  * None of them changes an image.  Values: same-box sweeps over four scenes in the multi-frame regime,
  * profiles/r02/experiments/.  (Compiling them in as immediates instead of launch arguments was measured: no difference.) */
