@@ -1,7 +1,7 @@
 // Issue cost of packed-f32 VALU instructions against plain ones on one CU (development tool): W waves per SIMD, each a
 // stream of 8 independent chains of ONE instruction kind; prints shader cycles per wave-instruction per wave and
 // wave-instructions per cycle per SIMD.  A v_pk_* instruction does two f32 operations per lane.
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench/pk_rate.hip -o tools/ubench/pk_rate && tools/ubench/pk_rate
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize tools/ubench/pk_rate.hip -o tools/ubench/pk_rate && tools/ubench/pk_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -20,22 +20,25 @@ __global__ void k(float *out, unsigned long long *cyc, float x)
     v2f a[CHAINS];
     double d[CHAINS];
     for (int i = 0; i < CHAINS; i++) { a[i].x = x + threadIdx.x + i; a[i].y = x * 0.5f + i; d[i] = a[i].x; }
-    const v2f m = {1.0001f, 0.9999f};
-    const double md = 1.0001;
+    const v2f m = {1.0001f * x, 0.9999f * x};          /* run-time values: nothing folds */
+    const double md = 1.0001 * x;
     __syncthreads();
     unsigned long long t0 = __builtin_readcyclecounter();
-#pragma unroll 4
+    /* (unrolled far enough that the loop's own scalar instructions and branch are < 2 % of the stream: a first version
+     * unrolled the one-chain loop by 4 and measured 12 "cycles per dependent instruction", 7 of them loop overhead) */
+#pragma unroll 64
     for (int it = 0; it < N / CHAINS; it++) {
 #pragma unroll
         for (int i = 0; i < CHAINS; i++) {
-            if (OP == OP_MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i].x) : "v"(m.x));
-            if (OP == OP_FMA) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[i].x) : "v"(m.x));
-            if (OP == OP_MIN) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i].x) : "v"(m.x));
-            if (OP == OP_MAX3) asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(a[i].x) : "v"(m.x));
-            if (OP == OP_PK_MUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
-            if (OP == OP_PK_ADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
-            if (OP == OP_PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(m));
-            if (OP == OP_MUL_F64) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[i]) : "v"(md));
+            /* plain C, not inline asm: the compiler pads every asm statement with an s_nop (hazard recognizer), which a
+             * first version of this benchmark counted as instruction latency */
+            if (OP == OP_MUL) a[i].x = a[i].x * m.x;
+            if (OP == OP_FMA) a[i].x = __builtin_fmaf(a[i].x, m.x, m.x);
+            if (OP == OP_MAX3) a[i].x = __builtin_fmaxf(__builtin_fmaxf(a[i].x, m.x), m.y);
+            if (OP == OP_PK_MUL) a[i] = a[i] * m;
+            if (OP == OP_PK_ADD) a[i] = a[i] + m;
+            if (OP == OP_PK_FMA) a[i] = __builtin_elementwise_fma(a[i], m, m);
+            if (OP == OP_MUL_F64) d[i] = d[i] * md;
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -71,7 +74,6 @@ int main()
     (void)hipMalloc(&out, 8192); (void)hipMalloc(&cyc, 8);
     run<OP_MUL>("v_mul_f32", out, cyc);
     run<OP_FMA>("v_fma_f32", out, cyc);
-    run<OP_MIN>("v_min_f32", out, cyc);
     run<OP_MAX3>("v_max3_f32", out, cyc);
     run<OP_PK_MUL>("v_pk_mul_f32", out, cyc);
     run<OP_PK_ADD>("v_pk_add_f32", out, cyc);
