@@ -367,8 +367,9 @@ private:
     }
 };
 
-/* Several GPUs of one node behind the same render() (rt_render_multi): device i of `devices` renders the
- * 8-row bands b with b % n == i, the bands meet on devices[0].  The image is the single-GPU image bit for
+/* Several GPUs of one node behind the same render() (rt_render_multi): every device of `devices` renders the 8x8
+ * tiles it owns - dealt out interleaved on the first call for a view, which measures them, and by measured cost
+ * from the second on - and the tiles meet on devices[0].  The image is the single-GPU image bit for
  * bit (a pixel depends only on its coordinates, its seed and its previous value, src/raytracer.cu:118-131).
  * The reference is single-GPU; this is what its main loop calls when the node has more than one. */
 class MultiRenderer {
@@ -417,6 +418,8 @@ public:
         check(ranks_[0].ctx, rt_render_multi(ranks_.data(), (int32_t)ranks_.size(), &cam.c, &rd.c, t.data(), (int32_t)t.size(), &fn, data->previous_render.data()));
         data->frame_num = fn;
     }
+    /* does GPU i exchange its tiles with the first GPU directly (xGMI peer access), or staged by the runtime? */
+    bool direct_peer_copies(int i) { return rt_peer_access(ranks_.at(0).ctx, ranks_.at((size_t)i).ctx) == 1; }
     /* the slowest rank's kernel time of the last call */
     float last_kernel_ms()
     {
