@@ -108,6 +108,7 @@ struct rt_ctx {
     size_t job_cap = 0;
     int job_frames = 0;                  /* what the uploaded schedule was built for (with order_key) */
     std::vector<DevList> dev_lists;
+    size_t dev_list_cap = 64;            /* cached tile lists before the cache is emptied; raised when one call needs more at once */
     /* knobs (RT_AMD_*), none changes an image */
     int heavy_top = 1024;                /* RT_AMD_HEAVY_TOP: the refined order moves that many tiles at most to the front (0 = never refine) */
     int lpt = 1;                         /* RT_AMD_LPT=0: the round-1 ticket order (heavy tiles of frame 0, 1, ... first) */
@@ -167,17 +168,16 @@ uint64_t fnv1a(const void *data, size_t bytes, uint64_t h = 1469598103934665603u
     return h;
 }
 
-#define RT_DEV_LIST_CACHE 64
-
 /* Room for `count` more cached tile lists on ctx's GPU (the current device).  A full cache is emptied as a whole - after
  * waiting for the device, so that no queued kernel still reads a list - which invalidates every pointer
  * device_tile_list has handed out: a caller that holds several at once (rt_render_multi_device) reserves first. */
 void reserve_tile_lists(rt_ctx *ctx, size_t count)
 {
-    if (ctx->dev_lists.size() + count <= RT_DEV_LIST_CACHE) return;
+    if (ctx->dev_lists.size() + count <= ctx->dev_list_cap) return;
     (void)hipDeviceSynchronize();
     for (DevList &dl : ctx->dev_lists) (void)hipFree(dl.d);
     ctx->dev_lists.clear();
+    if (count > ctx->dev_list_cap) ctx->dev_list_cap = count;      /* (more ranks than the cache had room for) */
 }
 
 /* `list` (host) on ctx's GPU.  A new list is uploaded on `stream` and the call waits for the upload (the source is the
