@@ -384,6 +384,14 @@ def test_flat_box_drop_quirk_on_the_device(rt, orc, ctx, models_dir):
     assert (frames["mesh"] != frames["brute"]).any(axis=2).sum() > 200        # the quirk is visible
 
 
+def test_frames_per_launch_follow_the_memory_budget(rt, ctx):
+    """rt_max_batch_frames: 32 planes of a 1080p or 2160p frame are nothing on a 288 GB GPU; 32 planes of the largest image the
+    ABI accepts (2^28 pixels, 3.2 GB a plane) would be 103 GB, more than the quarter of the memory the planes may take"""
+    assert ctx.max_batch_frames(1920, 1080) == 32 and ctx.max_batch_frames(3840, 2160) == 32
+    big = ctx.max_batch_frames(32768, 8192)
+    assert 1 <= big < 32
+
+
 def test_more_frames_than_one_launch_holds(rt, orc, models_dir):
     """40 progressive frames in one call: rt_render_frames and rt_render_multi cut them into launches of at most 32
     frames (RT_MAX_BATCH_FRAMES), the second launch continuing from the first one's image; both must equal the
