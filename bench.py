@@ -37,8 +37,10 @@ expensive tile alone takes ~95 % of a one-GPU frame), a sequence 
 overlaps its K x tiles/N tile-frames.  For N > 1 the line also carries, as extras, the weak-scaling
 measurement (image area grows with N at fixed aspect and field of view), BASELINE configs[4]
 (3840x2160, 4096 spp) and "capi_multi": the same K frames through rt_render_multi_device - the C ABI's
-one-host-thread path a C++ maintainer of the reference would call - from rank 0 over all visible GPUs,
-timed, with the peer-access status of every GPU pair and a bit-equality check against the gathered frame.
+one-host-thread path a C++ maintainer of the reference would call - over all visible GPUs while the ranks wait,
+timed, with the peer-access status of every GPU pair and a bit-equality check against the gathered frame (it
+runs in a child process with a time limit: that path has never seen two GPUs, and its first contact must not
+cost the run its headline).
 When WORLD_SIZE is not set and N > 1 this script starts its own N ranks (torch.distributed.run) before
 touching the GPU and relays rank 0's line.  If RCCL cannot initialise the run FAILS (exit code 3) unless
 --allow-gloo-fallback is given.
@@ -101,6 +103,7 @@ def parse_args(argv=None):
     ap.add_argument("--capi-multi", default=None, metavar="DEVICES",
                     help="also time rt_render_multi_device from ONE process over these devices (e.g. 0,0 rehearses two ranks on one GPU); "
                          "N > 1 does it over all visible GPUs unless --no-extras")
+    ap.add_argument("--capi-multi-child", action="store_true", help=argparse.SUPPRESS)     # internal: this process IS the capi_multi measurement
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frame-by-frame", action="store_true", help="one launch + one gather per step instead of multi-frame launches")
     ap.add_argument("--no-frame-by-frame-leg", action="store_true", help="skip the extra one-launch-per-step measurement (keeps a profile's launches all of one kind)")
@@ -252,6 +255,9 @@ def init_process_group(args, dev, world):
 
 def main():
     args = parse_args()
+    if args.capi_multi_child:
+        capi_multi_child(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args.gpus)
 
@@ -417,10 +423,7 @@ def main():
         capi_devices = [0] * world if args.share_gpu else list(range(min(world, torch.cuda.device_count())))
     if capi_devices:
         if rank == 0:
-            try:
-                extras["capi_multi"] = capi_multi(rt, torch, so, sky, capi_devices, W, H, spp, limit, args.warmup, args.steps, frame if batched else None)
-            except Exception as e:                      # noqa: BLE001  (a side measurement must not lose the headline)
-                extras["capi_multi"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            extras["capi_multi"] = capi_multi(args, capi_devices, W, H, spp, limit, frame if batched else None)
         if world > 1:
             dist.barrier(group=host_group)
 
@@ -507,21 +510,50 @@ def main():
         dist.destroy_process_group()
 
 
-def capi_multi(rt, torch, scene_objects, sky, devices, W, H, spp, limit, warmup, steps, reference_frame):
+def capi_multi(args, devices, W, H, spp, limit, reference_frame, timeout_s=300):
     """`steps` progressive frames through rt_render_multi_device (include/rt_amd.h; replaces run_ray_tracer
-    src/dispatch.cu:127-163 for a node) from THIS process over `devices`: one host thread, one context per entry,
-    cost-balanced tile lists, peer copies to devices[0].  Two untimed calls first (the view's first call measures
-    the tiles on an interleaved ownership, the second deals them out by cost), then the timed call renders frames
-    0..steps-1 into a fresh frame, which must equal `reference_frame` (the torch.distributed run's) bit for bit."""
+    src/dispatch.cu:127-163 for a node) over `devices` from ONE host thread - in a CHILD process with a time limit: the
+    peer-copy path has never run on more than one GPU, and whatever it does on its first real node (an exception, a
+    hang) must not cost the run its headline line.  The child prints a JSON object with the sha256 of its frame, which
+    must be the gathered frame's (the torch.distributed run's)."""
+    import hashlib
+    cmd = [sys.executable, os.path.abspath(__file__), "--capi-multi-child", "--capi-multi", ",".join(str(d) for d in devices), "--scene", args.scene,
+           "--width", str(W), "--height", str(H), "--spp", str(spp), "--limit", str(limit), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "no answer within %d s (child killed)" % timeout_s, "devices": devices}
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "child exit code %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]), "devices": devices}
+    out = json.loads(lines[-1])
+    if reference_frame is not None:
+        out["equals_gathered_frame"] = out.pop("frame_sha256") == hashlib.sha256(reference_frame.contiguous().cpu().numpy().tobytes()).hexdigest()
+    return out
+
+
+def capi_multi_child(args):
+    """the measurement itself (see capi_multi): one context per entry of --capi-multi, cost-balanced tile lists, peer copies to
+    the first device.  Two untimed calls first (the view's first call measures the tiles on an interleaved ownership, the
+    second deals them out by cost), then the timed call renders frames 0..steps-1 into a fresh frame."""
+    import hashlib
+    import importlib
+    import torch
+    rt = importlib.import_module("ray-tracer_amd")
+    devices = [int(x) for x in args.capi_multi.split(",")]
+    W, H, spp, limit, steps = args.width, args.height, args.spp, args.limit, args.steps
+    objs, sky = rt.scenes.CONFIG_SCENES[args.scene]()
+    so = rt.SceneObjects(objs)
     ctxs = [rt.Context(d) for d in devices]
-    scenes = [c.commit(scene_objects) for c in ctxs]
+    scenes = [c.commit(so) for c in ctxs]
     cam, rd = rt.Camera(W, H), rt.RenderData(spp, limit, True, sky)
     root = torch.device("cuda", devices[0])
     with torch.cuda.device(root):
         s0 = torch.cuda.current_stream(root).cuda_stream
         scratch = torch.zeros((H, W, 3), dtype=torch.float32, device=root)
         frame = torch.zeros((H, W, 3), dtype=torch.float32, device=root)
-        rt.render_multi_device(ctxs, scenes, cam, rd, [12345 + i for i in range(max(1, warmup))], 0, scratch.data_ptr(), stream=s0)
+        rt.render_multi_device(ctxs, scenes, cam, rd, [12345 + i for i in range(max(1, args.warmup))], 0, scratch.data_ptr(), stream=s0)
         rt.render_multi_device(ctxs, scenes, cam, rd, [12345], 0, scratch.data_ptr(), stream=s0)
 
         def sync():
@@ -533,15 +565,12 @@ def capi_multi(rt, torch, scene_objects, sky, devices, W, H, spp, limit, warmup,
         rt.render_multi_device(ctxs, scenes, cam, rd, [12345 + i for i in range(steps)], 0, frame.data_ptr(), stream=s0)
         sync()
         elapsed = time.perf_counter() - t0
-        out = {"entry": "rt_render_multi_device (one host thread, cost-balanced tile lists, peer copies to the first device)",
+        out = {"entry": "rt_render_multi_device (one host thread in a child process, cost-balanced tile lists, peer copies to the first device)",
                "devices": devices, "steps": steps, "value": W * H * spp * steps / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": elapsed / steps * 1e3,
                "kernel_ms_per_rank": [round(c.last_kernel_ms(), 3) for c in ctxs],
-               "p2p": [{"pair": [devices[0], d], "direct": bool(ctxs[0].peer_access(c) == 1)} for d, c in list(zip(devices, ctxs))[1:]]}
-        if reference_frame is not None:
-            ref = reference_frame.to(root).contiguous()
-            out["equals_gathered_frame"] = bool(torch.equal(frame.view(torch.int32), ref.view(torch.int32)))
-    del scenes, ctxs
-    return out
+               "p2p": [{"pair": [devices[0], d], "direct": bool(ctxs[0].peer_access(c) == 1)} for d, c in list(zip(devices, ctxs))[1:]],
+               "frame_sha256": hashlib.sha256(frame.cpu().numpy().tobytes()).hexdigest()}
+    print(json.dumps(out), flush=True)
 
 
 def weak_image(width, height, world):
