@@ -15,7 +15,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
+#include <set>
 #include <queue>
 #include <string>
 #include <vector>
@@ -141,6 +143,10 @@ struct rt_scene {
 };
 
 namespace {
+
+/* the live contexts: a root keeps a landing area per SOURCE context (rt_ctx::stages), which has to go when the source does */
+std::mutex g_ctx_mutex;
+std::set<rt_ctx *> g_live_ctxs;
 
 /* check_cuda_error src/utils.cu:5-10 */
 rt_status hip_fail(rt_ctx *ctx, hipError_t e, const char *what)
@@ -271,6 +277,10 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
         rt_ctx_destroy(ctx);
         return RT_ERR_HIP;
     }
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        g_live_ctxs.insert(ctx);
+    }
     *out = ctx;
     return RT_OK;
 }
@@ -278,6 +288,19 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
 extern "C" void rt_ctx_destroy(rt_ctx *ctx)
 {
     if (!ctx) return;
+    {
+        /* landing areas other contexts keep for this one (it was a rank of their multi-GPU calls) */
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        g_live_ctxs.erase(ctx);
+        for (rt_ctx *r : g_live_ctxs) {
+            auto it = r->stages.find(ctx);
+            if (it == r->stages.end()) continue;
+            (void)hipSetDevice(r->device);
+            if (it->second.ev_free) { (void)hipEventSynchronize(it->second.ev_free); (void)hipEventDestroy(it->second.ev_free); }
+            if (it->second.d) (void)hipFree(it->second.d);
+            r->stages.erase(it);
+        }
+    }
     (void)hipSetDevice(ctx->device);
     if (ctx->tile_counter) (void)hipFree(ctx->tile_counter);
     if (ctx->d_prev) (void)hipFree(ctx->d_prev);
