@@ -45,7 +45,7 @@
 /* Defaults of the render kernel's scheduling thresholds (lanes of a wave; see rt_kernel.hip; RT_AMD_* overrides them).
  * None of them changes an image.  Values: same-box sweeps over four scenes in the multi-frame regime,
  * profiles/r02/experiments/.  (Compiling them in as immediates instead of launch arguments was measured: no difference.) */
-#define RT_DEF_WORK_THRESHOLD 8      /* traversal steps run while at least this many lanes traverse */
+#define RT_DEF_WORK_THRESHOLD 4      /* traversal steps run while at least this many lanes traverse (4 against 8, round 3: -0.6 % monkey, -0.9 % cube, +-0 reference scene 0, an eighth of the image -1 %) */
 #define RT_DEF_READY_BREAK 40        /* ... unless this many lanes have cheap work (generate / fetch / next mesh / a miss) */
 #define RT_DEF_HIT_BREAK 24          /* ... or this many hold a hit to shade */
 #define RT_DEF_HIT_LOW 16            /* ... or at least this many hold a hit and, with the cheap-work lanes, they are */
