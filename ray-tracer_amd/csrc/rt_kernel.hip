@@ -70,6 +70,16 @@ enum { TM_CTL = 0, TM_SHADE = 1, TM_FETCH = 2, TM_GEN = 3, TM_MESH = 4, TM_DESCE
 #endif
 enum { ST_ITER = 0, ST_SHADE = 1, ST_SHADE_HIT = 2, ST_FETCH = 3, ST_GEN = 4, ST_MESH = 5, ST_MESH_START = 6, ST_WORK_ITER = 7, ST_NODE = 8, ST_LEAF_TRI = 9, ST_POP = 10, ST_DONE_MESH = 11, ST_N = 12 };
 
+#if defined(RT_STATS)
+#define RT_STAT_PARAMS , unsigned *st_exec, unsigned *st_lanes, int lane
+#define RT_STAT_ARGS , st_exec, st_lanes, lane
+#elif defined(RT_COSTMAP)
+#define RT_STAT_PARAMS , Px &p
+#define RT_STAT_ARGS , p
+#else
+#define RT_STAT_PARAMS
+#define RT_STAT_ARGS
+#endif
 #ifdef RT_STATS
 #define RT_STATS_FLUSH() do {                                                                              \
     for (int i = 0; i < ST_N; i++) {                                                                          \
@@ -85,6 +95,45 @@ enum { ST_ITER = 0, ST_SHADE = 1, ST_SHADE_HIT = 2, ST_FETCH = 3, ST_GEN = 4, ST
 #else
 #define RT_STATS_FLUSH() do { } while (0)
 #endif
+
+/* The descend loop of a traversal macro step: from an internal node down to a leaf (or to "no child entered").
+ * The body is branch-free: the deferred sibling is ALWAYS written to the slot above the top of the stack (one 8-byte
+ * LDS store) and the stack pointer moves only when both children are entered, so the only divergent branch of the
+ * loop is its exit.  The loop also ends, for everybody, once fewer than `descend_keep`/64 of the lanes that entered
+ * it are still descending: those lanes just stay on their internal node and go on next step, instead of making the
+ * others wait out the deepest descent of the wave.  MED3: box_enter_med3 (rays without a zero direction component). */
+template <int NT, bool MED3>
+__device__ __forceinline__ void rt_descend(uint32_t &cur, int &sp, uint2 *stack, int tid, const Lds &L, V3 o, V3 inv, float w_best, int descend_keep RT_STAT_PARAMS)
+{
+    const int n_enter = __popcll(__ballot(1));
+    const int n_keep = (n_enter * descend_keep) >> 6;
+    for (;;) {
+        RT_STAT(ST_NODE);
+        RT_COST(p.c_steps++);
+        const v4f *n = L.nodes + 4 * (int)(cur & RT_REF_NODE_MASK);
+        v4f q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+        float ld, rdist;
+        const bool l_push = MED3 ? box_enter_med3(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, w_best, ld)
+                                 : box_enter(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, w_best, ld);
+        const bool r_push = MED3 ? box_enter_med3(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, w_best, rdist)
+                                 : box_enter(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, w_best, rdist);
+        const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+        const bool l_first = ld < rdist;
+        /* Of two entered children the one pushed first (left when l_first) is visited second: it is the deferred
+         * sibling.  The other is popped immediately (its distance is still < best).  With one entered child that
+         * child is next and nothing is deferred. */
+        const bool both = l_push && r_push;
+        const bool entered = l_push || r_push;
+        const uint32_t deferred_ref = l_first ? lref : rref;
+        const float deferred_d = l_first ? ld : rdist;
+        stack[sp * NT + tid] = make_uint2(__float_as_uint(deferred_d), deferred_ref);
+        sp += both ? 1 : 0;
+        const uint32_t next = both ? (l_first ? rref : lref) : (l_push ? lref : rref);
+        cur = entered ? next : RT_REF_EMPTY_LEAF;
+        if (cur & RT_REF_LEAF) break;
+        if (__popcll(__ballot(1)) < n_keep) break;      /* wave-uniform */
+    }
+}
 
 /* MODE (RT_SCENE_*): where the scene is read from.  RT_SCENE_LDS: the whole blob is staged into LDS.  For scenes larger
  * than a CU's LDS the same code reads the triangles (RT_SCENE_HYBRID: the BVH nodes and the object records still fit) or
@@ -135,6 +184,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : RT_SMALL_WG_WAVES) void rt_ren
     uint32_t cur = 0;
     int sp = 0, w_prim = -1;
     float w_best = RT_INF_F;
+    bool w_zero_dir = false;     /* this traversal's ray has a direction component of exactly zero (box_enter_med3) */
     Chunk ch;
     ch.next = 0; ch.end = 0; ch.frame = 0; ch.exhausted = false;
 #ifdef RT_STATS
@@ -192,6 +242,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : RT_SMALL_WG_WAVES) void rt_ren
                 const bool rh = box_test(m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, p.o, p.inv, rd);
                 if (!rh || rd > RT_INF_F || ((root_ref & RT_REF_CHAIN) && !(rd < RT_INF_F))) continue;
                 cur = root_ref; sp = 0; w_best = RT_INF_F; w_prim = -1;
+                w_zero_dir = p.d.x == 0.0f || p.d.y == 0.0f || p.d.z == 0.0f;
                 p.mode = M_WAIT;
                 p.frame_steps |= 0x80000000u;           /* (cost bookkeeping: this pixel traverses) */
                 RT_STAT(ST_MESH_START);
@@ -232,41 +283,10 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : RT_SMALL_WG_WAVES) void rt_ren
                      * or a leaf whose triangles are tested and after which the stack is popped;
                      * "no child entered" is the empty leaf. */
                     if (!(cur & RT_REF_LEAF)) {
-                        /* The body is branch-free: the deferred sibling is ALWAYS written to the
-                         * slot above the top of the stack (one 8-byte LDS store) and the stack
-                         * pointer moves only when both children are entered, so the only
-                         * divergent branch of the loop is its exit.  The loop also ends, for
-                         * everybody, once fewer than `descend_keep`/64 of the lanes that entered
-                         * it are still descending: those lanes just stay on their internal node
-                         * and go on next step, instead of making the others wait out the deepest
-                         * descent of the wave. */
-                        const int n_enter = __popcll(__ballot(1));
-                        const int n_keep = (n_enter * a.descend_keep) >> 6;
-                        for (;;) {
-                            RT_STAT(ST_NODE);
-                            RT_COST(p.c_steps++);
-                            const v4f *n = L.nodes + 4 * (int)(cur & RT_REF_NODE_MASK);
-                            v4f q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
-                            float ld, rdist;
-                            const bool l_push = box_enter(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, w_best, ld);
-                            const bool r_push = box_enter(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, w_best, rdist);
-                            const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
-                            const bool l_first = ld < rdist;
-                            /* Of two entered children the one pushed first (left when l_first) is
-                             * visited second: it is the deferred sibling.  The other is popped
-                             * immediately (its distance is still < best).  With one entered child
-                             * that child is next and nothing is deferred. */
-                            const bool both = l_push && r_push;
-                            const bool entered = l_push || r_push;
-                            const uint32_t deferred_ref = l_first ? lref : rref;
-                            const float deferred_d = l_first ? ld : rdist;
-                            stack[sp * NT + tid] = make_uint2(__float_as_uint(deferred_d), deferred_ref);
-                            sp += both ? 1 : 0;
-                            const uint32_t next = both ? (l_first ? rref : lref) : (l_push ? lref : rref);
-                            cur = entered ? next : RT_REF_EMPTY_LEAF;
-                            if (cur & RT_REF_LEAF) break;
-                            if (__popcll(__ballot(1)) < n_keep) break;      /* wave-uniform */
-                        }
+                        /* two copies of the loop: the six-med3 slab test where no traversing ray of the wave has a direction
+                         * component of exactly zero (always, in practice), the reference's min / max form otherwise */
+                        if (__ballot(w_zero_dir) == 0ull) rt_descend<NT, true>(cur, sp, stack, tid, L, o, inv, w_best, a.descend_keep RT_STAT_ARGS);
+                        else rt_descend<NT, false>(cur, sp, stack, tid, L, o, inv, w_best, a.descend_keep RT_STAT_ARGS);
                     }
                     RT_LAP_SPLIT(TM_DESCEND)
                     if (cur & RT_REF_LEAF) {

@@ -97,6 +97,31 @@ __device__ __forceinline__ bool box_enter(float bx0, float by0, float bz0, float
     return tmin < fminf(tmax, best);
 }
 
+/* The same decision and, where the box is entered, the same entry distance from six v_med3_f32 instead of ten
+ * min / max (round 4; the kernel is bound by instruction issue and min / max / med3 / compares cost twice an add or a
+ * multiply there).  clamp(t; a, b) = med3(a, b, t) puts t into the slab's interval [min(a,b), max(a,b)].
+ * phi = clamp_z o clamp_y o clamp_x is non-decreasing; the kernel enters iff phi(0) < phi(best):
+ *  - if the reference enters (tmin < min(tmax, best), tmin = max(0, near_k), tmax = min(INF, far_k)): every near_k <= tmin <
+ *    far_k, so clamping 0 from below only ever raises it to the next near_k: phi(0) = tmin, the SAME float (a maximum
+ *    selects one of its operands); likewise phi(best) = min(best, far_k) > tmin: entered, with the reference's distance;
+ *  - if it does not: the slabs' intervals are either disjoint somewhere (then phi is constant) or have a common
+ *    intersection [N, F] onto which phi clamps, and max(0, N) >= min(best, F) gives phi(0) >= phi(best); with phi
+ *    monotone that is equality: not entered.
+ * best <= RT_INF_F always (w_best starts there and only falls), so min(INF, ...) needs no instruction.  The argument
+ * needs every product to be a number: (b - o) * inv is NaN only for 0 * inf, i.e. a direction component of exactly 0
+ * (NaN directions never traverse); rays with one take box_enter (the caller checks, wave-uniformly). */
+__device__ __forceinline__ bool box_enter_med3(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
+                                               V3 o, V3 inv, float best, float &tmin_out)
+{
+    const float x0 = (bx0 - o.x) * inv.x, x1 = (bx1 - o.x) * inv.x;
+    const float y0 = (by0 - o.y) * inv.y, y1 = (by1 - o.y) * inv.y;
+    const float z0 = (bz0 - o.z) * inv.z, z1 = (bz1 - o.z) * inv.z;
+    const float lo = __builtin_amdgcn_fmed3f(z0, z1, __builtin_amdgcn_fmed3f(y0, y1, __builtin_amdgcn_fmed3f(x0, x1, 0.0f)));
+    const float hi = __builtin_amdgcn_fmed3f(z0, z1, __builtin_amdgcn_fmed3f(y0, y1, __builtin_amdgcn_fmed3f(x0, x1, best)));
+    tmin_out = lo;
+    return lo < hi;
+}
+
 /* Triangle::hit src/objects.cu:135-163 (Moller-Trumbore, two-sided, no early out) */
 __device__ __forceinline__ bool tri_test(const v4f *tris, int idx, V3 o, V3 d, float &t_out, float &u_out, float &v_out)
 {

@@ -446,6 +446,34 @@ def test_random_mixed_scenes(rt, orc, ctx, models_dir, seed):
     assert eq(got, want)
 
 
+@pytest.mark.parametrize("aa", [False, True])
+def test_rays_with_a_zero_direction_component(rt, orc, ctx, models_dir, aa):
+    """A direction component of exactly 0 makes 1/d infinite and (plane - origin) * (1/d) a NaN whenever the origin
+    lies ON a box plane.  The kernel's six-med3 slab test (rt_pixel.h box_enter_med3) is only proved equal to the
+    reference's min/max form (src/objects.cu:404-434, fminf/fmaxf drop a NaN operand) for products that are numbers, so
+    traversals of such rays take the min/max copy of the loop.  Here: a camera at the origin whose pixel grid puts a whole
+    column at x == 0 and a whole row at y == 0 (antialias off: the primary rays keep those zeros), meshes whose vertices -
+    hence leaf and inner boxes - have coordinates of exactly 0 in x and y, and a mirror-like ground so that bounced rays
+    start ON box planes too."""
+    rng = np.random.default_rng(5)
+    n = 160
+    tris = (rng.normal(0, 0.9, (n, 1, 3)) + rng.normal(0, 0.35, (n, 3, 3))).astype(np.float32)
+    tris[..., 2] -= 4.0
+    tris[rng.random((n, 3)) < 0.35, 0] = 0.0          # many vertices in the plane x == 0 ...
+    tris[rng.random((n, 3)) < 0.35, 1] = 0.0          # ... and y == 0
+    objs = [("mesh", tris.reshape(n, 9), ("standard", (0.8, 0.6, 0.4), 0.9)),
+            ("obj", "cube.obj", [("enlarge", 0.5), ("translate", 0.5, 0.5, -3.0)], ("standard", (0.3, 0.9, 0.5), 0.2)),   # faces in x == 0 and y == 0
+            ("sphere", (3.0, 4.0, -4.0), 1.5, ("emissive", (1.0, 1.0, 1.0), 6)),
+            ("quad", (-6, -2, 0), (6, -2, 0), (6, -2, -9), (-6, -2, -9), ("standard", (0.6, 0.6, 0.6), 1.0))]
+    W, H = 64, 48
+    cam = np.array([0, 0, 0, -4.0, 3.0, -8.0, 0.125, 0, 0, 0, -0.125, 0], np.float32)    # pixel (32, y): x == 0; (x, 24): y == 0
+    scene = ctx.commit(rt.SceneObjects(objs))
+    data = rt.VariableRenderData(W, H)
+    rt.render(ctx, scene, rt.Camera(W, H, floats=cam), rt.RenderData(6, 5, aa, (0.5, 0.7, 1.0)), data, 4242)
+    want = orc.Scene(objs, orc.MATH_DET, models_dir).render(cam, W, H, 6, 5, (0.5, 0.7, 1.0), time_ms=4242, antialias=aa)
+    assert eq(data.previous_render, want)
+
+
 @pytest.mark.parametrize("name", ["monkey", "three_sphere"])
 def test_tiny_and_thin_images(rt, orc, ctx, models_dir, name):
     """images smaller than one tile, one pixel wide or high, one pixel in total"""
