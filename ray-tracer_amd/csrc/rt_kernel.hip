@@ -111,13 +111,14 @@ __device__ __forceinline__ void rt_descend(uint32_t &cur, int &sp, uint2 *stack,
         RT_STAT(ST_NODE);
         RT_COST(p.c_steps++);
         const v4f *n = L.nodes + 4 * (int)(cur & RT_REF_NODE_MASK);
-        v4f q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+        const v4f q0 = n[0], q1 = n[1], q2 = n[2];
+        const uint2 refs = *(const uint2 *)(n + 3);          /* the two child references: 8 of the last 16 bytes */
         float ld, rdist;
         const bool l_push = MED3 ? box_enter_med3(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, w_best, ld)
                                  : box_enter(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, w_best, ld);
         const bool r_push = MED3 ? box_enter_med3(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, w_best, rdist)
                                  : box_enter(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, w_best, rdist);
-        const uint32_t lref = __float_as_uint(q3.x), rref = __float_as_uint(q3.y);
+        const uint32_t lref = refs.x, rref = refs.y;
         const bool l_first = ld < rdist;
         /* Of two entered children the one pushed first (left when l_first) is visited second: it is the deferred
          * sibling.  The other is popped immediately (its distance is still < best).  With one entered child that
@@ -130,8 +131,17 @@ __device__ __forceinline__ void rt_descend(uint32_t &cur, int &sp, uint2 *stack,
         sp += both ? 1 : 0;
         const uint32_t next = both ? (l_first ? rref : lref) : (l_push ? lref : rref);
         cur = entered ? next : RT_REF_EMPTY_LEAF;
-        if (cur & RT_REF_LEAF) break;
-        if (__popcll(__ballot(1)) < n_keep) break;      /* wave-uniform */
+        {
+            /* one divergent exit instead of a divergent and a wave-uniform one: the count of lanes still descending goes
+             * through a VGPR, so the compiler folds "fewer than n_keep remain" into the lane's own exit condition
+             * (7 scalar instructions and a branch per node step instead of 16 and 3: -2 % on the monkey,
+             * profiles/r04/experiments/keep_rule_single_exit.txt) */
+            const bool leaf = (int)cur < 0;
+            const int c = __popcll(__ballot(1)) - __popcll(__ballot(leaf));
+            int cv;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(cv) : "s"(c));
+            if (leaf || cv < n_keep) break;
+        }
     }
 }
 
@@ -147,7 +157,7 @@ __device__ __forceinline__ void rt_descend(uint32_t &cur, int &sp, uint2 *stack,
  * five waves per SIMD (<= 96 VGPRs; the allocator then lands on 79-80, which lets six be resident).  The launcher
  * asks the runtime how many workgroups of the chosen shape fit a CU (rt_kernel_blocks_per_cu). */
 template <int NT, bool HAS_MESH, int MODE>
-__global__ __launch_bounds__(NT, NT == 1024 ? 4 : RT_SMALL_WG_WAVES) void rt_render_kernel(const rt_kernel_args a)
+__global__ __launch_bounds__(NT, NT == 1024 ? 4 : (HAS_MESH ? RT_SMALL_WG_WAVES : RT_SMALL_WG_WAVES + 1)) void rt_render_kernel(const rt_kernel_args a)
 {
     extern __shared__ v4f lds_raw[];
     const int tid = threadIdx.x;

@@ -6,11 +6,16 @@
  * A path tracer turns a 1-ulp difference in one of those into a different hit/miss
  * decision, so "CPU result == GPU result" needs transcendentals that are the SAME
  * function on both sides.  Everything below is built only from IEEE-754 binary32
- * + - * / (plus integer bit operations, and binary64 + - * for the huge-argument
- * path of sin/cos), never from fma, so it evaluates bit-identically under
- *   gcc   -O2 -ffp-contract=off           (oracle "det" mode, host code)
+ * + - * / and fma (plus integer bit operations, and binary64 + - * for the huge-argument
+ * path of sin/cos and for asin), so it evaluates bit-identically under
+ *   gcc   -O2 -ffp-contract=off -mfma     (oracle "det" mode, host code)
  *   hipcc -O3 -ffp-contract=off gfx950    (device code; f32 denormals are on, / and sqrt
  *                                          are correctly rounded by default in HIP).
+ * The fused multiply-adds are EXPLICIT (RT_FMAF / RT_FMA: one rounding, the same on every
+ * IEEE platform; without -mfma the host falls back to libm's correctly rounded fmaf) and only
+ * inside these functions, which are this repository's own: the polynomials and the argument
+ * reduction cost a third fewer instructions on the GPU (round 4).  The compilers stay at
+ * -ffp-contract=off: the reference's own `a*b+c` expressions are two roundings everywhere.
  *
  * Accuracy (measured in tests/test_math.py against glibc): rt_logf <= 1 ulp on the
  * RNG's range, rt_sinf/rt_cosf <= 1 ulp absolute-in-[0,1] terms for |x| <= 3000.
@@ -28,6 +33,12 @@
 #define RT_HD __host__ __device__ static inline
 #else
 #define RT_HD static inline
+#endif
+
+#ifdef RT_MATH_NO_FMA        /* A/B builds only (tools/build_variants.py): the unfused forms, round 3's functions exactly */
+#define RT_FMAF(a, b, c) ((a) * (b) + (c))
+#else
+#define RT_FMAF(a, b, c) __builtin_fmaf((a), (b), (c))
 #endif
 
 RT_HD uint32_t rt_f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
@@ -82,10 +93,11 @@ RT_HD float rt_logf(float x)
     float f = rt_u2f(mb) - 1.0f;
     float s = f / (2.0f + f);
     float z = s * s;
-    float R = z * (0.6666666666666666f + z * (0.4f + z * (0.2857142857142857f + z * 0.2222222222222222f)));
+    float R = z * RT_FMAF(z, RT_FMAF(z, RT_FMAF(z, 0.2222222222222222f, 0.2857142857142857f), 0.4f), 0.6666666666666666f);
     float hfsq = 0.5f * f * f;
     float dk = (float)k;
-    return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+    float t = RT_FMAF(s, hfsq + R, dk * LN2_LO);
+    return RT_FMAF(dk, LN2_HI, f - (hfsq - t));
 }
 
 /* ---- sine / cosine -----------------------------------------------------------------
@@ -95,16 +107,16 @@ RT_HD float rt_logf(float x)
 RT_HD float rt__sin_k(float r)
 {
     float z = r * r;
-    float p = -1.6666666666666666e-01f + z * (8.3333333333333332e-03f + z * (-1.9841269841269841e-04f + z * 2.7557319223985893e-06f));
-    return r + r * (z * p);
+    float p = RT_FMAF(z, RT_FMAF(z, RT_FMAF(z, 2.7557319223985893e-06f, -1.9841269841269841e-04f), 8.3333333333333332e-03f), -1.6666666666666666e-01f);
+    return RT_FMAF(r, z * p, r);
 }
 
 RT_HD float rt__cos_k(float r)
 {
     float z = r * r;
-    float p = 4.1666666666666664e-02f + z * (-1.3888888888888889e-03f + z * (2.4801587301587302e-05f + z * -2.7557319223985888e-07f));
+    float p = RT_FMAF(z, RT_FMAF(z, RT_FMAF(z, -2.7557319223985888e-07f, 2.4801587301587302e-05f), -1.3888888888888889e-03f), 4.1666666666666664e-02f);
     float hz = 0.5f * z;
-    return 1.0f - (hz - (z * z) * p);
+    return 1.0f - RT_FMAF(-(z * z), p, hz);
 }
 
 /* returns quadrant (n mod 4) and writes the reduced argument */
@@ -119,12 +131,11 @@ RT_HD int rt__rem_pio2(float x, float *r_out)
     uint32_t ax = rt_f2u(x) & 0x7fffffffu;
     if (ax <= 0x3f490fdau) { *r_out = x; return 0; }      /* |x| <= pi/4 */
     if (ax < 0x45490000u) {                               /* |x| < 3216: n <= 2048 */
-        float t = x * TWO_OVER_PI;
-        float fn = (t + MAGIC) - MAGIC;
-        float r = x - fn * P1;
-        r = r - fn * P2;
-        r = r - fn * P3;
-        r = r - fn * P4;
+        float fn = RT_FMAF(x, TWO_OVER_PI, MAGIC) - MAGIC;
+        float r = RT_FMAF(-fn, P1, x);
+        r = RT_FMAF(-fn, P2, r);
+        r = RT_FMAF(-fn, P3, r);
+        r = RT_FMAF(-fn, P4, r);
         *r_out = r;
         return (int)fn & 3;
     }
@@ -170,7 +181,8 @@ RT_HD float rt_tanf(float x) { return rt_sinf(x) / rt_cosf(x); }
  * and by the sphere texture coordinates (src/objects.cu:84-85: float asin/acos, evaluated here
  * through the binary64 routines and rounded once).  asin(x) on |x| <= 1/2 is its Maclaurin
  * series through x^55 (terms fall by > 4x each; the remainder is below 2e-18); for 1/2 < |x| <= 1
- * asin(x) = pi/2 - 2 asin(sqrt((1-|x|)/2)).  Only IEEE + - * / sqrt. */
+ * asin(x) = pi/2 - 2 asin(sqrt((1-|x|)/2)).  Only IEEE + - * / sqrt.  (The binary64 Horner chain stays multiply-then-add:
+ * as 27 v_fma_f64 the compiler schedules it - and everything inlined around it - into 128 registers with spills.) */
 RT_HD double rt__asin_series(double x)
 {
     /* Horner, highest coefficient first; coefficients (2n)! / (4^n n!^2 (2n+1)) */

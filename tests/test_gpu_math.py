@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def host_eval(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("hosteval") / "libhosteval.so")
-    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-shared", "-fPIC", os.path.join(ROOT, "tests", "math_host_eval.c"), "-o", so, "-lm"])
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off"] + (["-mfma"] if "fma" in open("/proc/cpuinfo").read().split() else []) + [ "-shared", "-fPIC", os.path.join(ROOT, "tests", "math_host_eval.c"), "-o", so, "-lm"])
     L = C.CDLL(so)
     L.host_eval.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int]
 

@@ -41,10 +41,19 @@ def test_render_kernel_register_budget(rt, tmp_path):
         nt, mesh, mode = int(m.group(1)), m.group(2) == "1", int(m.group(3))
         lds = mode == 1
         report.append("NT=%4d mesh=%d mode=%d: %s" % (nt, mesh, mode, v))
-        assert v["vgpr_spill_count"] == 0 and v["agpr_count"] == 0, (name, v)
-        # the two shapes the three BASELINE 1080p configurations run: no scratch at all
-        if lds and (nt == 256 or (nt == 1024 and mesh)):
-            assert v["private_segment_fixed_size"] == 0, (name, v)
+        assert v["agpr_count"] == 0, (name, v)
+        if mesh or nt == 1024:
+            assert v["vgpr_spill_count"] == 0, (name, v)
+            # the mesh shapes two of the three BASELINE 1080p configurations run: no scratch at all
+            if lds and (nt == 256 or nt == 1024):
+                assert v["private_segment_fixed_size"] == 0, (name, v)
+        else:
+            # round 4: with rt_math.h's explicit fma the sphere kernels want 83 registers; compiled for six waves per SIMD
+            # (<= 80) they keep 5 values of the once-per-PIXEL fetch / store path in scratch (16 bytes per lane; no scratch
+            # instruction in the per-sample or per-bounce code: `grep -n scratch_` on the kernel's assembly shows the
+            # prologue and px_finish_pixel only).  Same-box A/B, three-sphere 8 x 256 spp: 139.4 ms against 142.1 ms at
+            # 83 registers / five waves (profiles/r04/experiments/fma_math.txt)
+            assert v["vgpr_spill_count"] <= 8 and v["private_segment_fixed_size"] <= 32, (name, v)
         if nt < 1024:
             # small workgroups are register-bound: <= 80 VGPRs lets six waves per SIMD be resident without a mesh
             # (512 / 80), <= 96 five with one (512 / 96)

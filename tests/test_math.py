@@ -83,7 +83,7 @@ def test_dense_accuracy_against_libm(tmp_path):
     import subprocess
     from conftest import ROOT
     exe = str(tmp_path / "math_accuracy")
-    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", os.path.join(ROOT, "tests", "math_accuracy.c"), "-o", exe, "-lm"])
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off"] + (["-mfma"] if "fma" in open("/proc/cpuinfo").read().split() else []) + [ os.path.join(ROOT, "tests", "math_accuracy.c"), "-o", exe, "-lm"])
     out = subprocess.run([exe, os.environ.get("RT_MATH_STRIDE", "1")], capture_output=True, text=True, timeout=900).stdout
     v = {k: float(x) for k, x in re.findall(r"(\w+) ([0-9.e+-]+)(?= |$)", out) if k != "at"}
     assert v["log_ulp"] <= 1.0, out                    # measured 0.983 ulp
