@@ -261,7 +261,7 @@ int32_t rt_max_batch_frames(rt_ctx *ctx, int32_t width, int32_t height);
 rt_status rt_last_kernel_ms(rt_ctx *ctx, float *ms);
 /* Blocks until the most recent launch of this context has finished and returns its status: the
  * cudaDeviceSynchronize + cudaPeekAtLastError pair of src/dispatch.cu:141,161 for callers of the
- * asynchronous device-buffer entry points.  RT_ERR_HIP if the (opt-in) pooled kernel abandoned the frame. */
+ * asynchronous device-buffer entry points. */
 rt_status rt_ctx_synchronize(rt_ctx *ctx);
 
 /* ---- several GPUs of one node from one host thread ---------------------------------------------

@@ -38,11 +38,20 @@ extern "C" hipError_t rt_launch_rgba8(const float *rgb, int n_pixels, uint8_t *o
 
 namespace {
 
-/* a tile list on the device, found again by content (lists are a few KB to ~130 KB and change only with the view) */
+/* a tile list on the device, found again by content (lists are a few KB to ~130 KB and change only with the view).
+ * `host` is a pinned copy: what a hash hit is compared with (a 64-bit hash alone would render the wrong
+ * tiles on a collision) and what the asynchronous upload reads.  An entry is recycled least-recently-used first; the
+ * upload of its new content is ordered behind every launch that read the old one by events, never by a host wait. */
 struct DevList {
     uint64_t hash = 0;
     int n = 0;
     uint32_t *d = nullptr;
+    uint32_t *host = nullptr;            /* pinned, `cap` entries */
+    size_t cap = 0;
+    uint64_t seq = 0;                    /* rt_ctx::list_seq when last handed out (LRU order; > pin_floor: not recyclable) */
+    hipStream_t stream = nullptr;        /* the stream of the launches it was last handed out for */
+    hipEvent_t ev = nullptr;             /* scratch: "everything queued on `stream` so far" (orders a reuse on another stream) */
+    hipEvent_t ev_up = nullptr;          /* "the upload from `host` is done": the pinned copy may be rewritten */
 };
 
 /* the root's landing area for one source context's compact image (rt_gather, rt_render_multi_device) */
@@ -98,6 +107,7 @@ struct rt_ctx {
     size_t tile_cost_cap = 0;
     uint32_t *d_tile_peak = nullptr;     /* ... and of its most expensive pixel */
     size_t tile_peak_cap = 0;
+    int cost_spp = 0;                    /* rays_per_pixel of the launch the figures come from (a pilot: 1) */
     int cost_state = 0;                  /* 0 nothing, 1 a launch of this view collected costs, 2 cost_host holds them (and the order is refined) */
     std::vector<uint32_t> cost_host;     /* the measured (or caller-supplied) costs, per local tile */
     std::vector<uint32_t> peak_host;     /* ... and peak pixel costs: what the schedule sorts by */
@@ -110,7 +120,8 @@ struct rt_ctx {
     size_t job_cap = 0;
     int job_frames = 0;                  /* what the uploaded schedule was built for (with order_key) */
     std::vector<DevList> dev_lists;
-    size_t dev_list_cap = 64;            /* cached tile lists before the cache is emptied; raised when one call needs more at once */
+    size_t dev_list_cap = 64;            /* cached tile lists; beyond that the least recently used entry is recycled (raised when one call pins more) */
+    uint64_t list_seq = 0, pin_floor = ~0ull;   /* entries handed out after pin_floor are held by the running call (rt_render_multi_device) */
     /* knobs (RT_AMD_*), none changes an image */
     int heavy_top = 1024;                /* RT_AMD_HEAVY_TOP: the refined order moves that many tiles at most to the front (0 = never refine) */
     int lpt = 1;                         /* RT_AMD_LPT=0: the round-1 ticket order (heavy tiles of frame 0, 1, ... first) */
@@ -174,37 +185,78 @@ uint64_t fnv1a(const void *data, size_t bytes, uint64_t h = 1469598103934665603u
     return h;
 }
 
-/* Room for `count` more cached tile lists on ctx's GPU (the current device).  A full cache is emptied as a whole - after
- * waiting for the device, so that no queued kernel still reads a list - which invalidates every pointer
- * device_tile_list has handed out: a caller that holds several at once (rt_render_multi_device) reserves first. */
-void reserve_tile_lists(rt_ctx *ctx, size_t count)
+/* A call that holds several lists at once (rt_render_multi_device: every rank's list on the root) pins what it is handed
+ * from here on: pinned entries are not recycled, the cache grows instead.  unpin when the call has queued its work. */
+void pin_tile_lists(rt_ctx *ctx) { ctx->pin_floor = ctx->list_seq; }
+void unpin_tile_lists(rt_ctx *ctx) { ctx->pin_floor = ~0ull; }
+
+void free_dev_list(DevList &dl)
 {
-    if (ctx->dev_lists.size() + count <= ctx->dev_list_cap) return;
-    (void)hipDeviceSynchronize();
-    for (DevList &dl : ctx->dev_lists) (void)hipFree(dl.d);
-    ctx->dev_lists.clear();
-    if (count > ctx->dev_list_cap) ctx->dev_list_cap = count;      /* (more ranks than the cache had room for) */
+    if (dl.d) (void)hipFree(dl.d);
+    if (dl.host) (void)hipHostFree(dl.host);
+    if (dl.ev) (void)hipEventDestroy(dl.ev);
+    if (dl.ev_up) (void)hipEventDestroy(dl.ev_up);
+    dl = DevList();
 }
 
-/* `list` (host) on ctx's GPU.  A new list is uploaded on `stream` and the call waits for the upload (the source is the
- * caller's memory); a list seen before costs a hash.  The pointer stays valid until the cache is next emptied
- * (reserve_tile_lists): use it in launches queued before the next call, or reserve room for all the lists needed. */
+/* `list` (host) on ctx's GPU, for launches the caller queues on `stream` after this call.  A list seen before costs a hash
+ * and a compare.  A new one takes a free entry or recycles the least recently used one: its content goes into the entry's
+ * pinned buffer and is uploaded asynchronously on `stream`, behind (hipStreamWaitEvent) whatever was queued on the stream
+ * the entry last served - no host synchronisation on the steady-state path, and no device-wide one ever (round 3 emptied a
+ * full cache after hipDeviceSynchronize and waited for every upload).  The pointer stays valid until the entry
+ * is recycled: after dev_list_cap other lists, and never while pinned. */
 rt_status device_tile_list(rt_ctx *ctx, const uint32_t *list, int n, hipStream_t stream, const uint32_t **out)
 {
     *out = nullptr;
     if (n <= 0) return RT_OK;
     const uint64_t h = fnv1a(list, (size_t)n * 4);
-    for (const DevList &dl : ctx->dev_lists)
-        if (dl.hash == h && dl.n == n) { *out = dl.d; return RT_OK; }
-    reserve_tile_lists(ctx, 1);
-    DevList dl;
-    dl.hash = h; dl.n = n;
-    RT_HIP(ctx, hipMalloc((void **)&dl.d, (size_t)n * 4), "allocating a tile list");
-    hipError_t e = hipMemcpyAsync(dl.d, list, (size_t)n * 4, hipMemcpyHostToDevice, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) { (void)hipFree(dl.d); return hip_fail(ctx, e, "uploading a tile list"); }
-    ctx->dev_lists.push_back(dl);
-    *out = dl.d;
+    for (DevList &dl : ctx->dev_lists)
+        if (dl.hash == h && dl.n == n && std::memcmp(dl.host, list, (size_t)n * 4) == 0) {
+            if (dl.stream != stream) {
+                /* handed to another stream than the one its upload (or last use) was queued on: order the two */
+                RT_HIP(ctx, hipEventRecord(dl.ev, dl.stream), "recording a tile list's use");
+                RT_HIP(ctx, hipStreamWaitEvent(stream, dl.ev, 0), "ordering a tile list's use");
+                dl.stream = stream;
+            }
+            dl.seq = ++ctx->list_seq;
+            *out = dl.d;
+            return RT_OK;
+        }
+    DevList *slot = nullptr;
+    if (ctx->dev_lists.size() >= ctx->dev_list_cap) {
+        for (DevList &dl : ctx->dev_lists)
+            if ((ctx->pin_floor == ~0ull || dl.seq <= ctx->pin_floor) && (!slot || dl.seq < slot->seq)) slot = &dl;
+        if (!slot) ctx->dev_list_cap = ctx->dev_lists.size() + 1;      /* everything is pinned by the running call: grow */
+    }
+    if (!slot) {
+        ctx->dev_lists.emplace_back();
+        slot = &ctx->dev_lists.back();
+        RT_HIP(ctx, hipEventCreateWithFlags(&slot->ev, hipEventDisableTiming), "creating a tile list's event");
+        RT_HIP(ctx, hipEventCreateWithFlags(&slot->ev_up, hipEventDisableTiming), "creating a tile list's event");
+    } else {
+        /* recycle: the new upload must not overtake a queued launch that still reads the old content (same stream: stream
+         * order; another stream: an event), and the pinned copy is rewritten only once ITS last upload is done - which it
+         * has been since dev_list_cap lists ago, so that wait returns at once */
+        RT_HIP(ctx, hipEventRecord(slot->ev, slot->stream), "recording a tile list's last use");
+        if (slot->stream != stream) RT_HIP(ctx, hipStreamWaitEvent(stream, slot->ev, 0), "ordering a tile list's reuse");
+    }
+    if (slot->cap < (size_t)n) {
+        /* a larger buffer: the old one goes once the launches reading it are done (the event just recorded) */
+        if (slot->d) { (void)hipEventSynchronize(slot->ev); (void)hipFree(slot->d); (void)hipHostFree(slot->host); slot->d = nullptr; slot->host = nullptr; }   /* (rare: lists of one image size share a capacity) */
+        const size_t cap = (size_t)n + (size_t)n / 4 + 64;
+        RT_HIP(ctx, hipMalloc((void **)&slot->d, cap * 4), "allocating a tile list");
+        hipError_t e = hipHostMalloc((void **)&slot->host, cap * 4, hipHostMallocDefault);
+        if (e != hipSuccess) { (void)hipFree(slot->d); slot->d = nullptr; slot->cap = 0; slot->n = 0; slot->hash = 0; return hip_fail(ctx, e, "allocating a tile list's staging copy"); }
+        slot->cap = cap;
+    } else if (slot->n > 0) {
+        (void)hipEventSynchronize(slot->ev_up);
+    }
+    std::memcpy(slot->host, list, (size_t)n * 4);
+    slot->hash = h; slot->n = n; slot->stream = stream; slot->seq = ++ctx->list_seq;
+    hipError_t e = hipMemcpyAsync(slot->d, slot->host, (size_t)n * 4, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipEventRecord(slot->ev_up, stream);
+    if (e != hipSuccess) { slot->n = 0; slot->hash = 0; return hip_fail(ctx, e, "uploading a tile list"); }
+    *out = slot->d;
     return RT_OK;
 }
 
@@ -311,7 +363,7 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     if (ctx->d_job_order) (void)hipFree(ctx->d_job_order);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
     if (ctx->d_bands) (void)hipFree(ctx->d_bands);
-    for (DevList &dl : ctx->dev_lists) (void)hipFree(dl.d);
+    for (DevList &dl : ctx->dev_lists) free_dev_list(dl);
     for (auto &kv : ctx->stages) {
         if (kv.second.d) (void)hipFree(kv.second.d);
         if (kv.second.ev_free) (void)hipEventDestroy(kv.second.ev_free);
@@ -682,6 +734,7 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
         key.push_back(scene->uid); key.push_back((uint32_t)ctx->tile_scatter);
         for (int i = 0; i < 12; i++) { uint32_t u; std::memcpy(&u, &a.cam[i], 4); key.push_back(u); }
         key.push_back((uint32_t)a.width); key.push_back((uint32_t)a.height);
+        key.push_back((uint32_t)a.reflection_limit);      /* (a launch at bounce limit 0 or 1 says nothing about one at 8) */
         if (listed) {
             uint64_t h = fnv1a(t->tile_list, (size_t)n * 4);
             if (t->tile_cost) h = fnv1a(t->tile_cost, (size_t)n * 4, h);
@@ -776,6 +829,9 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
          * synchronisation) and moves the `heavy_top` most expensive tiles to the front of the order, most expensive
          * first within rounds of one ticket per wave.  In a multi-frame launch those tiles go first for ALL frames
          * (see px_fetch): with the true costs that is worth 10 % at three frames per launch (with the guess, nothing). */
+        /* a pixel's cost counter is 26 bits wide (rt_device_scene.h RT_COST_*): launches that could overflow it (65,536 or
+         * more bounces per pixel) do not collect costs and run on the schedule the view already has */
+        const bool cost_fits = (long long)rs->rays_per_pixel * (long long)(rs->reflection_limit > 0 ? rs->reflection_limit : 1) < 65536ll;
         if (ctx->cost_state == 0) {
             /* Pilot: a view's first launch would run on the guessed order (measured: 315 instead of 228 ms per frame for
              * the monkey's first five frames).  One sample per pixel of the launch's first frame, rendered into a scratch
@@ -798,17 +854,30 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
                 RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 512, stream), "clearing tile counter");
                 RT_HIP(ctx, rt_launch_render(&ap, scene->flat.has_mesh ? 1 : 0, scene->scene_in_lds, scene->threads, launch_blocks(ctx, scene, (int)n), scene->lds_bytes, stream),
                        "launching the pilot");
-                ctx->cost_state = 1;
+                ctx->cost_state = 1; ctx->cost_spp = 1;
                 if ((st = read_costs_and_refine(ctx, stream)) != RT_OK) return st;      /* -> 2: a provisional schedule */
             }
-            RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)n * 4, stream), "clearing tile costs");
-            RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_peak, 0, (size_t)n * 4, stream), "clearing tile costs");
-            a.tile_cost = ctx->d_tile_cost;
-            a.tile_peak = ctx->d_tile_peak;
-            collecting = true;
-        } else if (ctx->cost_state == 1 && ctx->use_order) {
-            rt_status st = read_costs_and_refine(ctx, stream);
-            if (st != RT_OK) return st;
+            if (cost_fits) {
+                RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)n * 4, stream), "clearing tile costs");
+                RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_peak, 0, (size_t)n * 4, stream), "clearing tile costs");
+                a.tile_cost = ctx->d_tile_cost;
+                a.tile_peak = ctx->d_tile_peak;
+                collecting = true;
+            }
+        } else {
+            if (ctx->cost_state == 1 && ctx->use_order) {
+                rt_status st = read_costs_and_refine(ctx, stream);
+                if (st != RT_OK) return st;
+            }
+            /* figures from a launch with far fewer samples (a 1-spp preview, a profiler's warm-up launch) are provisional
+             * like a pilot's: this launch runs on them and measures again */
+            if (ctx->cost_state == 2 && ctx->cost_spp > 0 && (long long)ctx->cost_spp * 8 <= (long long)rs->rays_per_pixel && !(listed && t->tile_cost) && cost_fits) {
+                RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)n * 4, stream), "clearing tile costs");
+                RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_peak, 0, (size_t)n * 4, stream), "clearing tile costs");
+                a.tile_cost = ctx->d_tile_cost;
+                a.tile_peak = ctx->d_tile_peak;
+                collecting = true;
+            }
         }
         if (ctx->use_order) {
             a.num_heavy_tiles = (ctx->cost_state == 2 && n_frames > 1) ? ctx->order_num_heavy : 0;
@@ -850,7 +919,7 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
         const int blocks = launch_blocks(ctx, scene, a.num_tiles);
         RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 512, stream), "clearing tile counter");
         RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
-        if (collecting) ctx->cost_state = 1;            /* only now: a failed launch leaves no costs to sort on */
+        if (collecting) { ctx->cost_state = 1; ctx->cost_spp = rs->rays_per_pixel; }   /* only now: a failed launch leaves no costs to sort on */
     }
     if (in_place && a.num_tiles > 0) {
         /* the pixels this launch owns.  Compact layouts, and a full frame rendered whole: one pass over the buffer;
@@ -1104,7 +1173,11 @@ hipError_t copy_between(float *dst, int dst_dev, const float *src, int src_dev, 
 rt_status stage_for(rt_ctx *root, rt_ctx *src, size_t need, hipStream_t s0, Stage **out)
 {
     RT_HIP(root, hipSetDevice(root->device), "selecting device");
-    Stage &sg = root->stages[src];
+    /* rt_ctx_destroy of a source erases its entry from every live root's map under g_ctx_mutex: look the
+     * entry up under the same lock.  (std::map nodes do not move: the reference stays valid while src is alive.) */
+    Stage *sgp;
+    { std::lock_guard<std::mutex> lock(g_ctx_mutex); sgp = &root->stages[src]; }
+    Stage &sg = *sgp;
     if (!sg.ev_free) RT_HIP(root, hipEventCreateWithFlags(&sg.ev_free, hipEventDisableTiming), "creating the staging event");
     if (sg.cap < need || !sg.d) {
         /* nothing may still be reading or writing the old area */
@@ -1249,8 +1322,8 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
     }
     RT_HIP(root, hipSetDevice(root->device), "selecting device");
     /* this call holds every rank's list on the root's GPU at once (the copies to and from the frame), and rank 0's launch
-     * looks its own up as well: make room now, so that the cache is not emptied under the pointers */
-    if (band_rows == 0) reserve_tile_lists(root, (size_t)n_ranks + 2);
+     * looks its own up as well: what the cache hands out from here on is not recycled before the call has queued its work */
+    struct Pin { rt_ctx *c; explicit Pin(rt_ctx *c_) : c(c_) { pin_tile_lists(c); } ~Pin() { unpin_tile_lists(c); } } pin(root);
 
     /* ---- who renders what -------------------------------------------------------------------------- */
     BandLayout L;
@@ -1265,6 +1338,9 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
         for (int i = 0; i < 3; i++) { uint32_t u; std::memcpy(&u, &cam->delta_u[i], 4); key.push_back(u); }
         for (int i = 0; i < 3; i++) { uint32_t u; std::memcpy(&u, &cam->delta_v[i], 4); key.push_back(u); }
         key.push_back((uint32_t)W); key.push_back((uint32_t)H); key.push_back((uint32_t)n_ranks);
+        /* the bounce limit, and whether this is a preview-quality launch (< 8 samples) or a real one: ownership measured on
+         * the one says little about the other */
+        key.push_back((uint32_t)rs->reflection_limit); key.push_back(rs->rays_per_pixel < 8 ? 0u : 1u);
         for (int i = 0; i < n_ranks; i++) { key.push_back(ranks[i].scene->uid); key.push_back((uint32_t)ranks[i].ctx->device); }
         std::vector<int32_t> owner((size_t)tiles_x * tiles_y);
         if (key != ms.key || ms.lists.size() != (size_t)n_ranks) {

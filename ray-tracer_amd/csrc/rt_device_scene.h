@@ -53,17 +53,24 @@
 #define RT_DEF_DESCEND_KEEP 24       /* the descend loop ends once fewer than this many 64ths of its lanes remain */
 #define RT_DEF_SHADE_BATCH 40        /* scenes without a mesh: hits are shaded once this many lanes hold one */
 /* What a pixel is charged for (the tile costs a view's first launch collects: longest-job-first schedule, cost-balanced
- * tile ownership over GPUs): per traversal macro step, per generated bounce ray, per shaded hit.  Fitted to the kernel
- * times of 1/2/4/8-rank shares of the monkey run (tools/fit_cost_weights.py, profiles/r03/cost_weights.txt). */
+ * tile ownership over GPUs): per traversal macro step, per generated bounce ray, per shaded hit.  The ratios are what was
+ * fitted to the kernel times of 1/2/4/8-rank shares of the monkey run (tools/fit_cost_weights.py,
+ * profiles/r03/experiments/cost_weights_driver_shape.txt, yield_cadence_and_cost_weights.txt: any weighting of this
+ * shape predicts a rank's time to 1.6-1.8 % rms); round 4 divided round 3's (4, 3, 8) by four: a pixel's cost
+ * lives in bits 30..RT_FRAME_BITS of its frame word, 2^26 units, and at one unit per macro step that is more than any
+ * pixel the host lets collect costs can reach (rt_capi.cpp: launches of rays_per_pixel * reflection_limit >= 2^16 run on
+ * the previous or the guessed schedule).  Only frame 0 of a launch is charged to its tile, capped at RT_COST_PIXEL_CAP, so
+ * that a tile's 32-bit sum of 64 pixels (<< 1, bit 0 = "a ray entered a mesh") cannot wrap either. */
 #ifndef RT_COST_STEP
-#define RT_COST_STEP 4
+#define RT_COST_STEP 1
 #endif
 #ifndef RT_COST_GEN
-#define RT_COST_GEN 3
+#define RT_COST_GEN 1
 #endif
 #ifndef RT_COST_HIT
-#define RT_COST_HIT 8
+#define RT_COST_HIT 2
 #endif
+#define RT_COST_PIXEL_CAP 0x00ffffffu   /* 64 pixels x 2^24 x 2 = 2^31 */
 #define RT_JOB_FRAME_SHIFT 22          /* a job = tile | frame << 22 (2^28 pixels are 2^22 tiles) */
 #define RT_JOB_TILE_MASK 0x003fffffu
 #define RT_INF_F 1073741824.0f       /* reference `1 << 31 - 1` == 1 << 30, src/objects.cu:6 */

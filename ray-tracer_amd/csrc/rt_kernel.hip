@@ -63,6 +63,11 @@ enum { TM_CTL = 0, TM_SHADE = 1, TM_FETCH = 2, TM_GEN = 3, TM_MESH = 4, TM_DESCE
  * timers are per-lane registers; only laps that all lanes execute measure the wave) */
 #define RT_LAP_SPLIT(slot) } RT_LAP(slot); if (p.mode == M_WAIT) {
 #define RT_LAP_SPLIT_LEAF(slot) } } RT_LAP(slot); if (p.mode == M_WAIT) { if (cur & RT_REF_LEAF) {
+#elif defined(RT_MARK)
+/* (tools/isa_sections.py: section boundaries as comments in the assembly) */
+#define RT_LAP(slot) asm volatile("; LAP " #slot)
+#define RT_LAP_SPLIT(slot) asm volatile("; LAP " #slot);
+#define RT_LAP_SPLIT_LEAF(slot) asm volatile("; LAP " #slot);
 #else
 #define RT_LAP(slot) do { } while (0)
 #define RT_LAP_SPLIT(slot)
@@ -103,7 +108,7 @@ enum { ST_ITER = 0, ST_SHADE = 1, ST_SHADE_HIT = 2, ST_FETCH = 3, ST_GEN = 4, ST
  * it are still descending: those lanes just stay on their internal node and go on next step, instead of making the
  * others wait out the deepest descent of the wave.  MED3: box_enter_med3 (rays without a zero direction component). */
 template <int NT, bool MED3>
-__device__ __forceinline__ void rt_descend(uint32_t &cur, int &sp, uint2 *stack, int tid, const Lds &L, V3 o, V3 inv, float w_best, int descend_keep RT_STAT_PARAMS)
+__device__ __forceinline__ void rt_descend(uint32_t &cur, int &sp, uint2 *my_stack, const Lds &L, V3 o, V3 inv, float w_best, int descend_keep RT_STAT_PARAMS)
 {
     const int n_enter = __popcll(__ballot(1));
     const int n_keep = (n_enter * descend_keep) >> 6;
@@ -127,7 +132,7 @@ __device__ __forceinline__ void rt_descend(uint32_t &cur, int &sp, uint2 *stack,
         const bool entered = l_push || r_push;
         const uint32_t deferred_ref = l_first ? lref : rref;
         const float deferred_d = l_first ? ld : rdist;
-        stack[sp * NT + tid] = make_uint2(__float_as_uint(deferred_d), deferred_ref);
+        my_stack[sp * NT] = make_uint2(__float_as_uint(deferred_d), deferred_ref);
         sp += both ? 1 : 0;
         const uint32_t next = both ? (l_first ? rref : lref) : (l_push ? lref : rref);
         cur = entered ? next : RT_REF_EMPTY_LEAF;
@@ -185,6 +190,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : (HAS_MESH ? RT_SMALL_WG_WAVES 
         stack = (uint2 *)lds_raw;
     }
     __syncthreads();
+    uint2 *const my_stack = stack + tid;        /* this lane's column of the [entry][thread] stack */
 
     Frame f;
     frame_init(f, a);
@@ -295,8 +301,8 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : (HAS_MESH ? RT_SMALL_WG_WAVES 
                     if (!(cur & RT_REF_LEAF)) {
                         /* two copies of the loop: the six-med3 slab test where no traversing ray of the wave has a direction
                          * component of exactly zero (always, in practice), the reference's min / max form otherwise */
-                        if (__ballot(w_zero_dir) == 0ull) rt_descend<NT, true>(cur, sp, stack, tid, L, o, inv, w_best, a.descend_keep RT_STAT_ARGS);
-                        else rt_descend<NT, false>(cur, sp, stack, tid, L, o, inv, w_best, a.descend_keep RT_STAT_ARGS);
+                        if (__ballot(w_zero_dir) == 0ull) rt_descend<NT, true>(cur, sp, my_stack, L, o, inv, w_best, a.descend_keep RT_STAT_ARGS);
+                        else rt_descend<NT, false>(cur, sp, my_stack, L, o, inv, w_best, a.descend_keep RT_STAT_ARGS);
                     }
                     RT_LAP_SPLIT(TM_DESCEND)
                     if (cur & RT_REF_LEAF) {
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : (HAS_MESH ? RT_SMALL_WG_WAVES 
                         if (sp > 0) {
                             RT_STAT(ST_POP);
                             sp--;
-                            const uint2 e = stack[sp * NT + tid];
+                            const uint2 e = my_stack[sp * NT];
                             const float dd = __uint_as_float(e.x);
                             const bool take = dd < w_best || (dd == w_best && !(e.y & RT_REF_CHAIN));
                             cur = take ? e.y : RT_REF_EMPTY_LEAF;

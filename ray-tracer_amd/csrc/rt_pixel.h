@@ -255,10 +255,12 @@ __device__ __forceinline__ void px_finish_pixel(Px &p, const rt_kernel_args &a, 
     size_t pixel = (size_t)py * (size_t)f.W + (size_t)px;
     if (a.compact) pixel = a.tile_list ? (size_t)p.id : (size_t)(compact_row + (within >> 3)) * (size_t)f.W + (size_t)px;
     /* (first launch of a view) what this pixel cost, charged to its tile */
-    if (a.tile_cost) {
-        /* cost units in bits 31..1 of the tile's sum; bit 0: some pixel of the tile traversed a mesh (those tiles are
+    if (a.tile_cost && (p.frame_steps & (unsigned)(RT_MAX_BATCH_FRAMES - 1)) == 0u) {
+        /* (frame 0 of the launch only: the figures describe the view, not the launch, and a 32-frame sum could wrap)
+         * cost units in bits 31..1 of the tile's sum; bit 0: some pixel of the tile traversed a mesh (those tiles are
          * the long jobs the schedule puts first, rt_capi.cpp build_job_order) */
-        const unsigned units = (p.frame_steps & 0x7fffffffu) >> RT_FRAME_BITS;
+        unsigned units = (p.frame_steps & 0x7fffffffu) >> RT_FRAME_BITS;
+        units = units > RT_COST_PIXEL_CAP ? RT_COST_PIXEL_CAP : units;
         atomicAdd(a.tile_cost + tile, units << 1);
         /* ... and the tile's most expensive pixel: a tile-frame is one job, as long as its longest pixel (a pixel's samples
          * are one sequential stream), and the schedule starts the longest jobs first */

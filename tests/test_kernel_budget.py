@@ -18,6 +18,16 @@ def kernel_notes(rt, tmp_path):
     subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
     txt = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True)
+    # scratch INSTRUCTIONS per kernel (the descriptor can reserve a few bytes of private segment that no instruction touches)
+    dis = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", co], text=True)
+    scratch_insts, cur = {}, None
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            cur = m.group(1)
+            scratch_insts[cur] = 0
+        elif cur and re.search(r"\bscratch_(load|store)", line):
+            scratch_insts[cur] += 1
     out = {}
     for blk in txt.split("- .agpr_count:")[1:]:
         def g(k):
@@ -25,6 +35,7 @@ def kernel_notes(rt, tmp_path):
             return m.group(1) if m else None
         out[g("name")] = {k: int(g(k)) for k in ("vgpr_count", "vgpr_spill_count", "sgpr_count", "sgpr_spill_count", "private_segment_fixed_size")}
         out[g("name")]["agpr_count"] = int(blk.split()[0])
+        out[g("name")]["scratch_insts"] = scratch_insts.get(g("name"), -1)
     return out
 
 
@@ -44,16 +55,16 @@ def test_render_kernel_register_budget(rt, tmp_path):
         assert v["agpr_count"] == 0, (name, v)
         if mesh or nt == 1024:
             assert v["vgpr_spill_count"] == 0, (name, v)
-            # the mesh shapes two of the three BASELINE 1080p configurations run: no scratch at all
-            if lds and (nt == 256 or nt == 1024):
-                assert v["private_segment_fixed_size"] == 0, (name, v)
+            # no scratch instruction anywhere in the mesh kernels (the descriptor may still reserve a few bytes: round 4's
+            # builds show 36 for the LDS shapes with zero VGPR spills and not one scratch_load / scratch_store)
+            assert v["scratch_insts"] == 0 and v["private_segment_fixed_size"] <= 64, (name, v)
         else:
             # round 4: with rt_math.h's explicit fma the sphere kernels want 83 registers; compiled for six waves per SIMD
             # (<= 80) they keep 5 values of the once-per-PIXEL fetch / store path in scratch (16 bytes per lane; no scratch
             # instruction in the per-sample or per-bounce code: `grep -n scratch_` on the kernel's assembly shows the
             # prologue and px_finish_pixel only).  Same-box A/B, three-sphere 8 x 256 spp: 139.4 ms against 142.1 ms at
             # 83 registers / five waves (profiles/r04/experiments/fma_math.txt)
-            assert v["vgpr_spill_count"] <= 8 and v["private_segment_fixed_size"] <= 32, (name, v)
+            assert v["vgpr_spill_count"] <= 8 and v["private_segment_fixed_size"] <= 32 and 0 <= v["scratch_insts"] <= 8, (name, v)
         if nt < 1024:
             # small workgroups are register-bound: <= 80 VGPRs lets six waves per SIMD be resident without a mesh
             # (512 / 80), <= 96 five with one (512 / 96)
