@@ -104,6 +104,7 @@ def parse_args(argv=None):
                     help="also time rt_render_multi_device from ONE process over these devices (e.g. 0,0 rehearses two ranks on one GPU); "
                          "N > 1 does it over all visible GPUs unless --no-extras")
     ap.add_argument("--capi-multi-child", action="store_true", help=argparse.SUPPRESS)     # internal: this process IS the capi_multi measurement
+    ap.add_argument("--capi-self-test", action="store_true", help=argparse.SUPPRESS)        # internal: the child stops after its 4-spp first contact and prints that frame's hash
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frame-by-frame", action="store_true", help="one launch + one gather per step instead of multi-frame launches")
     ap.add_argument("--no-frame-by-frame-leg", action="store_true", help="skip the extra one-launch-per-step measurement (keeps a profile's launches all of one kind)")
@@ -112,6 +113,11 @@ def parse_args(argv=None):
     ap.add_argument("--allow-gloo-fallback", action="store_true", help="if RCCL cannot initialise, measure through gloo + host memory instead of failing")
     ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (rehearsal on a one-GPU box)")
     ap.add_argument("--check", action="store_true", help="rank 0 also renders the frames alone and checks the gathered frame equals it bit for bit")
+    ap.add_argument("--self-test", action="store_true",
+                    help="N > 1 (on by default there unless --no-extras): before anything is timed, 2 frames at 4 spp through BOTH multi-GPU drivers "
+                         "(process group + gather, and rt_render_multi_device in a child) must equal rank 0 rendering alone, bit for bit")
+    ap.add_argument("--no-self-test", action="store_true")
+    ap.add_argument("--no-host-group", action="store_true", help=argparse.SUPPRESS)      # rehearsal: behave as if the gloo side group could not be created
     args = ap.parse_args(argv)
     scene, W, H, spp, limit = CONFIGS[args.config]
     args.scene = args.scene or scene
@@ -280,15 +286,21 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     backend, backend_note = "none", None
-    host_group = None
+    host_group, host_group_kind = None, "none"
     if world > 1:
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")       # one node by contract: gloo over loopback, whatever the hostname resolves to
         backend, backend_note = init_process_group(args, dev, world)
         # a host-side group for waiting without occupying the GPU (an RCCL barrier is a kernel that spins on every rank's GPU)
-        try:
-            host_group = dist.new_group(backend="gloo") if backend != "gloo" else None
-        except Exception:                               # noqa: BLE001  (then the waiting ranks spin in an RCCL barrier: slower capi_multi, same results)
-            host_group = None
+        host_group_kind = "gloo"                        # what the ranks wait in while rank 0's child uses their GPUs
+        if backend != "gloo":
+            try:
+                if args.no_host_group:
+                    raise RuntimeError("--no-host-group")
+                host_group = dist.new_group(backend="gloo")
+            except Exception:                           # noqa: BLE001
+                # without a host-side group the only way to wait is an RCCL barrier - a kernel spinning on the very GPUs the
+                # capi_multi child renders on.  Then that measurement runs AFTER the process group is gone (see below).
+                host_group, host_group_kind = None, "none"
 
     rt = importlib.import_module("ray-tracer_amd")
     dm = importlib.import_module("ray-tracer_amd.distributed")
@@ -317,7 +329,7 @@ def main():
         cam = rt.Camera(W, H)
         rd = rt.RenderData(spp, limit, True, sky)
         max_batch = min(MAX_BATCH, ctx.max_batch_frames(W, H))
-        kernel_ms, frames_per_launch = [], []
+        kernel_ms, frames_per_launch, gather_ms = [], [], []
         part = {"kind": "tile lists (cost-balanced)" if use_lists else "bands of 8 rows"}
 
         def run(n, record, lists, hints, local, gathered):
@@ -325,9 +337,18 @@ def main():
                 else dict(band_first=rank, band_stride=world, compact=True)
 
             def collect():
+                # the exchange on its own clock (events on the current stream, where dist.gather and the tile scatter are
+                # queued): a lost scaling point can then be put down to the gather or to the kernels from the one line
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
                 if lists is not None:
-                    return dm.gather_tiles(local, lists, W, H, rank, world, ctx=ctx, dst=0, out=gathered, stream=stream)
-                return dm.gather_frame(local, W, H, band_rows, rank, world, dst=0, out=gathered)
+                    f = dm.gather_tiles(local, lists, W, H, rank, world, ctx=ctx, dst=0, out=gathered, stream=stream)
+                else:
+                    f = dm.gather_frame(local, W, H, band_rows, rank, world, dst=0, out=gathered)
+                e1.record()
+                if record and world > 1:
+                    gather_ms.append((e0, e1))
+                return f
             if batched:
                 launches = (n + max_batch - 1) // max_batch
                 done = 0
@@ -384,10 +405,14 @@ def main():
                 t = t.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        torch.cuda.synchronize()
         return {"elapsed": elapsed, "frame": frame, "kernel_ms": kernel_ms, "frames_per_launch": frames_per_launch, "cam": cam, "rd": rd,
-                "my_pixels": my_pixels, "partition": part}
+                "my_pixels": my_pixels, "partition": part, "gather_ms": [a.elapsed_time(b) for a, b in gather_ms]}
 
     W, H, spp, limit = args.width, args.height, args.spp, args.limit
+    self_test = None
+    if world > 1 and not args.no_self_test and (args.self_test or not args.no_extras):
+        self_test = run_self_test(args, rt, dm, ctx, scene, sky, dev, rank, world, stream, measure, host_group, host_group_kind)
     if world > 1 and args.scaling == "weak":
         W, H = weak_image(args.width, args.height, world)
     batched = not args.frame_by_frame
@@ -421,11 +446,12 @@ def main():
         capi_devices = [int(x) for x in args.capi_multi.split(",")]
     elif world > 1 and not args.no_extras and batched:
         capi_devices = [0] * world if args.share_gpu else list(range(min(world, torch.cuda.device_count())))
-    if capi_devices:
+    capi_after_group = capi_runs_after_group(bool(capi_devices), world, backend, host_group is not None)
+    if capi_devices and not capi_after_group:
         if rank == 0:
             extras["capi_multi"] = capi_multi(args, capi_devices, W, H, spp, limit, frame if batched else None)
         if world > 1:
-            dist.barrier(group=host_group)
+            dist.barrier(group=host_group)          # gloo: the waiting ranks sleep in a socket, their GPUs are the child's
 
     samples_per_step = W * H * spp
     value = samples_per_step * args.steps / elapsed / 1e6
@@ -453,7 +479,7 @@ def main():
     ranks_info = None
     if world > 1:
         mine = {"rank": rank, "device": torch.cuda.get_device_name(local_rank), "local_rank": local_rank,
-                "kernel_ms": [round(x, 3) for x in kernel_ms]}
+                "kernel_ms": [round(x, 3) for x in kernel_ms], "gather_ms": [round(x, 3) for x in m["gather_ms"]]}
         allr = [None] * world
         dist.all_gather_object(allr, mine)
         ranks_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": allr, "partition": m["partition"]}
@@ -475,6 +501,19 @@ def main():
            "roofline": roofline}
     if ranks_info is not None:
         out["ranks"] = ranks_info
+        out["host_group"] = host_group_kind
+        g = m["gather_ms"]
+        out["gather_ms"] = (sum(g) / len(g)) if g else None        # rank 0: dist.gather + the scatter of every rank's tiles into the frame, per measurement
+        out["gather_ms_note"] = "events on rank 0's stream around dist.gather and the tile scatter; includes waiting for the slowest rank's kernel"
+    if self_test is not None:
+        out["self_test"] = self_test
+    if capi_after_group:
+        # no host-side group: rank 0 runs the one-thread driver only once the process group (and with it every RCCL kernel) is gone
+        frame_ref = frame if batched else None
+        dist.destroy_process_group()
+        if rank == 0:
+            extras["capi_multi"] = capi_multi(args, capi_devices, W, H, spp, limit, frame_ref)
+            extras["capi_multi"]["ran"] = "after destroy_process_group (no gloo side group to wait in)"
     if extras:
         out["extras"] = extras
     if per_frame is not None:
@@ -506,11 +545,51 @@ def main():
                 torch.cuda.synchronize()
                 out["gathered_equals_single_launch"] = bool(torch.equal(frame.contiguous().view(torch.int32), x.view(torch.int32)))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 and not capi_after_group:
         dist.destroy_process_group()
 
 
-def capi_multi(args, devices, W, H, spp, limit, reference_frame, timeout_s=300):
+def capi_runs_after_group(have_devices, world, backend, have_host_group):
+    """When does rank 0 run the one-host-thread driver (rt_render_multi_device in a child, on ALL GPUs)?  While the other ranks
+    wait for it - which must not occupy their GPUs: a gloo barrier sleeps in a socket, an RCCL barrier is a kernel spinning
+    on every GPU.  So: under the barrier if the waiting is host-side (a gloo process group, or the gloo side group beside RCCL);
+    otherwise only after destroy_process_group, when no collective can be running any more.  -> True for the latter."""
+    return bool(have_devices) and world > 1 and backend != "gloo" and not have_host_group
+
+
+def run_self_test(args, rt, dm, ctx, scene, sky, dev, rank, world, stream, measure, host_group, host_group_kind):
+    """Before anything is timed: 2 progressive frames at 4 samples per pixel of the run's image through BOTH multi-GPU drivers -
+    this process group (tile lists or bands + dist.gather) and the C ABI's rt_render_multi_device in a child of rank 0 - against
+    rank 0 rendering the two frames alone.  Seconds of work; a wrong or hanging exchange is then known before the long legs,
+    and the line says which driver it was."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    W, H, limit = args.width, args.height, args.limit
+    res = {"workload": "2 frames at 4 spp of the run's image", "process_group": None, "capi_multi": None}
+    m = measure(W, H, 4, limit, 1, 2, True)
+    sha = None
+    if rank == 0:
+        cam, rd = rt.Camera(W, H), rt.RenderData(4, limit, True, sky)
+        alone = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        rt.render_device_batch(ctx, scene, cam, rd, [12345, 12346], 0, alone.data_ptr(), stream=stream)
+        torch.cuda.synchronize()
+        res["process_group"] = bool(torch.equal(m["frame"].contiguous().view(torch.int32), alone.view(torch.int32)))
+        sha = hashlib.sha256(alone.cpu().numpy().tobytes()).hexdigest()
+    if host_group_kind == "gloo" or dist.get_backend() == "gloo":
+        # (without a host-side group the child would share its GPUs with a spinning RCCL barrier: the C ABI's leg of the
+        # self-test is then left to the timed capi_multi run, which checks its frame as well)
+        if rank == 0:
+            devices = [0] * world if args.share_gpu else list(range(min(world, torch.cuda.device_count())))
+            r = capi_multi(args, devices, W, H, 4, limit, None, timeout_s=120, self_test=True)
+            res["capi_multi"] = (r.get("frame_sha256") == sha) if "error" not in r else r
+        dist.barrier(group=host_group)
+    else:
+        res["capi_multi"] = "skipped: no host-side group (checked by the timed capi_multi run instead)"
+    return res
+
+
+def capi_multi(args, devices, W, H, spp, limit, reference_frame, timeout_s=300, self_test=False):
     """`steps` progressive frames through rt_render_multi_device (include/rt_amd.h; replaces run_ray_tracer
     src/dispatch.cu:127-163 for a node) over `devices` from ONE host thread - in a CHILD process with a time limit: the
     peer-copy path has never run on more than one GPU, and whatever it does on its first real node (an exception, a
@@ -519,6 +598,8 @@ def capi_multi(args, devices, W, H, spp, limit, reference_frame, timeout_s=300):
     import hashlib
     cmd = [sys.executable, os.path.abspath(__file__), "--capi-multi-child", "--capi-multi", ",".join(str(d) for d in devices), "--scene", args.scene,
            "--width", str(W), "--height", str(H), "--spp", str(spp), "--limit", str(limit), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if self_test:
+        cmd.append("--capi-self-test")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK")}
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, timeout=timeout_s)
@@ -526,7 +607,10 @@ def capi_multi(args, devices, W, H, spp, limit, reference_frame, timeout_s=300):
         return {"error": "no answer within %d s (child killed)" % timeout_s, "devices": devices}
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:
-        return {"error": "child exit code %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]), "devices": devices}
+        err = {"error": "child exit code %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:]), "devices": devices}
+        if lines:                                   # the child's own account: phase, every rank's rt_last_error
+            err.update(json.loads(lines[-1]))
+        return err
     out = json.loads(lines[-1])
     if reference_frame is not None:
         out["equals_gathered_frame"] = out.pop("frame_sha256") == hashlib.sha256(reference_frame.contiguous().cpu().numpy().tobytes()).hexdigest()
@@ -549,22 +633,49 @@ def capi_multi_child(args):
     scenes = [c.commit(so) for c in ctxs]
     cam, rd = rt.Camera(W, H), rt.RenderData(spp, limit, True, sky)
     root = torch.device("cuda", devices[0])
+    phase = "start"
+
+    def fail(e):
+        # which call was being made, and what every rank's context last complained about (rt_last_error names the step that was
+        # being queued: scatter-out, launch, peer copy, de-interleave)
+        print(json.dumps({"error": "%s: %s" % (type(e).__name__, str(e)[:300]), "phase": phase, "devices": devices,
+                          "last_errors": [c.last_error() for c in ctxs]}), flush=True)
+        sys.exit(4)
+
     with torch.cuda.device(root):
         s0 = torch.cuda.current_stream(root).cuda_stream
         scratch = torch.zeros((H, W, 3), dtype=torch.float32, device=root)
         frame = torch.zeros((H, W, 3), dtype=torch.float32, device=root)
-        rt.render_multi_device(ctxs, scenes, cam, rd, [12345 + i for i in range(max(1, args.warmup))], 0, scratch.data_ptr(), stream=s0)
-        rt.render_multi_device(ctxs, scenes, cam, rd, [12345], 0, scratch.data_ptr(), stream=s0)
 
         def sync():
             torch.cuda.synchronize(root)
             for c in ctxs:
                 c.synchronize()
-        sync()
-        t0 = time.perf_counter()
-        rt.render_multi_device(ctxs, scenes, cam, rd, [12345 + i for i in range(steps)], 0, frame.data_ptr(), stream=s0)
-        sync()
-        elapsed = time.perf_counter() - t0
+        try:
+            # first contact at 4 samples per pixel: a hang or a fault on the peer-copy path shows in seconds, not at the time limit
+            phase = "first contact: 2 frames at 4 spp (measuring call, interleaved ownership)"
+            rd4 = rt.RenderData(4, limit, True, sky)
+            rt.render_multi_device(ctxs, scenes, cam, rd4, [12345, 12346], 0, scratch.data_ptr(), stream=s0)
+            sync()
+            phase = "first contact: 2 frames at 4 spp (balanced ownership)"
+            rt.render_multi_device(ctxs, scenes, cam, rd4, [12345, 12346], 0, scratch.data_ptr(), stream=s0)
+            sync()
+            small_sha = hashlib.sha256(scratch.cpu().numpy().tobytes()).hexdigest()
+            if args.capi_self_test:
+                print(json.dumps({"devices": devices, "frame_sha256": small_sha, "phase": "self-test"}), flush=True)
+                return
+            phase = "warm-up at full sample count (measuring call)"
+            rt.render_multi_device(ctxs, scenes, cam, rd, [12345 + i for i in range(max(1, args.warmup))], 0, scratch.data_ptr(), stream=s0)
+            phase = "warm-up at full sample count (balanced ownership)"
+            rt.render_multi_device(ctxs, scenes, cam, rd, [12345], 0, scratch.data_ptr(), stream=s0)
+            sync()
+            phase = "timed call"
+            t0 = time.perf_counter()
+            rt.render_multi_device(ctxs, scenes, cam, rd, [12345 + i for i in range(steps)], 0, frame.data_ptr(), stream=s0)
+            sync()
+            elapsed = time.perf_counter() - t0
+        except Exception as e:                      # noqa: BLE001
+            fail(e)
         out = {"entry": "rt_render_multi_device (one host thread in a child process, cost-balanced tile lists, peer copies to the first device)",
                "devices": devices, "steps": steps, "value": W * H * spp * steps / elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": elapsed / steps * 1e3,
                "kernel_ms_per_rank": [round(c.last_kernel_ms(), 3) for c in ctxs],

@@ -536,6 +536,11 @@ class Context:
                 raise ValueError(msg)
             raise RayTracerError(msg)
 
+    def last_error(self):
+        """the context's most recent error message (rt_last_error; empty when there was none)"""
+        m = lib().rt_last_error(self._h)
+        return m.decode() if m else ""
+
     def commit(self, scene_objects):
         return Scene(self, scene_objects)
 

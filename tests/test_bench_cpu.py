@@ -91,3 +91,17 @@ def test_bench_refuses_to_run_without_a_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0 and "no GPU" in (r.stderr + r.stdout) and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_capi_multi_never_runs_under_an_rccl_barrier():
+    """if the gloo side group cannot be created, the waiting ranks must not sit in an RCCL barrier (a kernel
+    spinning on GPUs 1..N-1) while rank 0's child renders on those GPUs: the child then runs after destroy_process_group."""
+    import bench
+    f = bench.capi_runs_after_group
+    assert f(True, 8, "nccl", False) is True          # RCCL, no side group: after the group is gone
+    assert f(True, 8, "nccl", True) is False          # RCCL + gloo side group: under the host-side barrier
+    assert f(True, 2, "gloo", False) is False         # a gloo process group waits host-side by itself
+    assert f(False, 8, "nccl", False) is False        # nothing to run
+    assert f(True, 1, "none", False) is False         # one GPU: --capi-multi runs inline
+    a = bench.parse_args(["--gpus", "2", "--no-host-group", "--self-test"])
+    assert a.no_host_group and a.self_test and not a.no_self_test
