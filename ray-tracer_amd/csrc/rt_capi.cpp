@@ -451,6 +451,7 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
          * LDS holds only the traversal stacks */
         s->scene_in_lds = RT_SCENE_GLOBAL;
         s->threads = s->flat.has_mesh ? 1024 : 256;
+        if (s->flat.has_mesh) { const char *gt = getenv("RT_AMD_GLOBAL_THREADS"); if (gt && atoi(gt) == 256) s->threads = 256; }   /* development: 5 x 256 instead of 1 x 1024 */
         s->lds_bytes = per_thread * (size_t)s->threads;
         if (s->lds_bytes > RT_LDS_LIMIT) {
             delete s;

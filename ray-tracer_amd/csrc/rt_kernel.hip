@@ -130,8 +130,9 @@ __device__ __forceinline__ void rt_descend(uint32_t &cur, int &sp, uint2 *my_sta
          * child is next and nothing is deferred. */
         const bool both = l_push && r_push;
         const bool entered = l_push || r_push;
-        const uint32_t deferred_ref = l_first ? lref : rref;
-        const float deferred_d = l_first ? ld : rdist;
+        const unsigned long long l_first_lanes = __builtin_amdgcn_fcmpf(ld, rdist, RT_FCMP_OLT);
+        const uint32_t deferred_ref = rt_sel_u32(l_first_lanes, lref, rref);
+        const float deferred_d = rt_sel_f32(l_first_lanes, ld, rdist);
         my_stack[sp * NT] = make_uint2(__float_as_uint(deferred_d), deferred_ref);
         sp += both ? 1 : 0;
         const uint32_t next = both ? (l_first ? rref : lref) : (l_push ? lref : rref);
@@ -312,9 +313,10 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : (HAS_MESH ? RT_SMALL_WG_WAVES 
                         for (int k = 0; k < count; k++) {
                             RT_STAT(ST_LEAF_TRI);
                             RT_COST(p.c_steps++);
-                            float t, u, v;
-                            bool h = tri_test(L.tris, start + k, o, d, t, u, v);
-                            if (h && t < w_best) { w_best = t; w_prim = start + k; }
+                            float t;
+                            const unsigned long long closer = tri_closer_lanes(L.tris, start + k, o, d, w_best, t);
+                            w_best = rt_sel_f32(closer, t, w_best);
+                            w_prim = (int)rt_sel_u32(closer, (uint32_t)(start + k), (uint32_t)w_prim);
                         }
                         RT_LAP_SPLIT_LEAF(TM_LEAF)
                         /* pop one entry: it is taken iff !(dist > best) (:501); through a
@@ -495,6 +497,7 @@ extern "C" int rt_kernel_blocks_per_cu(int has_mesh, int scene_in_lds, int threa
 {
     if (scene_in_lds == RT_SCENE_GLOBAL) {
         if (has_mesh && threads == 1024) return rt_blocks_one<1024, true, RT_SCENE_GLOBAL>(lds_bytes);
+        if (has_mesh && threads == 256) return rt_blocks_one<256, true, RT_SCENE_GLOBAL>(lds_bytes);
         if (!has_mesh && threads == 256) return rt_blocks_one<256, false, RT_SCENE_GLOBAL>(lds_bytes);
         return 0;
     }
@@ -528,6 +531,7 @@ extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh,
     if (scene_in_lds == RT_SCENE_GLOBAL) {
         /* global-memory scene: one shape per mesh flag is enough */
         if (has_mesh && threads == 1024) rt_launch_one<1024, true, RT_SCENE_GLOBAL>(args, blocks, lds_bytes, stream);
+        else if (has_mesh && threads == 256) rt_launch_one<256, true, RT_SCENE_GLOBAL>(args, blocks, lds_bytes, stream);
         else if (!has_mesh && threads == 256) rt_launch_one<256, false, RT_SCENE_GLOBAL>(args, blocks, lds_bytes, stream);
         else return hipErrorInvalidValue;
         return hipGetLastError();

@@ -61,6 +61,18 @@ struct Lds {
     const v4f *objtab;   /* the object list (rt_object, 3 x 16 B each), read with wave-uniform addresses */
 };
 
+/* c ? a : b as a v_cndmask_b32 in its VOP3 form (mask from an SGPR pair).  The compiler prefers the VOP2 form, which reads
+ * the mask from VCC - and two of THOSE back to back cost the issuing wave 16 cycles each instead of 4 on gfx950
+ * (tools/ubench/valu_tput.hip K_CNDMASK / K_CC2 against K_CNDMASK_S / K_CC2S; profiles/r04/experiments/valu_tput.txt).
+ * Used where the traversal loops select two values on one condition. */
+__device__ __forceinline__ uint32_t rt_sel_u32(unsigned long long lanes, uint32_t a, uint32_t b)       /* lanes = __ballot(condition) */
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(lanes));
+    return r;
+}
+__device__ __forceinline__ float rt_sel_f32(unsigned long long lanes, float a, float b) { return __uint_as_float(rt_sel_u32(lanes, __float_as_uint(a), __float_as_uint(b))); }
+
 /* BoundingBox::ray_hits src/objects.cu:404-434.  fminf/fmaxf drop a NaN operand like CUDA's
  * min/max; the result only ever feeds comparisons, so the sign of a zero is irrelevant. */
 __device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
@@ -138,6 +150,33 @@ __device__ __forceinline__ bool tri_test(const v4f *tris, int idx, V3 o, V3 d, f
     float dist = dot(s2, q_vec) * inv_det;
     t_out = dist; u_out = u; v_out = v;
     return dist > RT_EPS_F && u >= 0.0f && v >= 0.0f && w >= 0.0f;
+}
+
+/* The same test for the traversal's leaf loop, with the outcome as a lane mask (compares written straight to SGPR pairs and
+ * combined there): which lanes' rays hit AND are closer than `best`.  (__ballot of a bool built from several compares costs a
+ * v_cndmask and a v_cmp to rebuild the mask.) */
+#define RT_FCMP_OGT 2
+#define RT_FCMP_OGE 3
+#define RT_FCMP_OLT 4
+__device__ __forceinline__ unsigned long long tri_closer_lanes(const v4f *tris, int idx, V3 o, V3 d, float best, float &t_out)
+{
+    float t, u, v;
+    v4f q0 = tris[3 * idx], q1 = tris[3 * idx + 1], q2 = tris[3 * idx + 2];
+    V3 p0 = v3(q0.x, q0.y, q0.z), s1 = v3(q0.w, q1.x, q1.y), s2 = v3(q1.z, q1.w, q2.x);
+    V3 p_vec = cross(d, s2);
+    float det = dot(s1, p_vec);
+    float inv_det = 1.0f / det;
+    V3 t_vec = o - p0;
+    u = dot(t_vec, p_vec) * inv_det;
+    V3 q_vec = cross(t_vec, s1);
+    v = dot(d, q_vec) * inv_det;
+    float w = 1.0f - u - v;
+    t = dot(s2, q_vec) * inv_det;
+    t_out = t;
+    /* u >= 0 && v >= 0 && w >= 0 is one compare of v_minimum3_f32 (gfx950; IEEE-754-2019 minimum: a NaN operand gives NaN,
+     * which fails the compare exactly as it fails its own; -0 >= 0 holds either way) */
+    const float m = __builtin_elementwise_minimum(__builtin_elementwise_minimum(u, v), w);
+    return __builtin_amdgcn_fcmpf(t, RT_EPS_F, RT_FCMP_OGT) & __builtin_amdgcn_fcmpf(m, 0.0f, RT_FCMP_OGE) & __builtin_amdgcn_fcmpf(t, best, RT_FCMP_OLT);
 }
 
 /* Quad::hit src/objects.cu:223-236 — t1 if it hits, whatever t2's distance; else t2 */
@@ -545,6 +584,8 @@ __device__ __forceinline__ void px_gen(Px &p, const rt_kernel_args &a, const Lds
         /* rt_object from LDS: every lane reads the same address (broadcast) */
         const v4f ob0 = L.objtab[3 * i], ob1 = L.objtab[3 * i + 1], ob2 = L.objtab[3 * i + 2];
         rt_object ob;
+        /* (the record is the same for every lane, but sending its type through an SGPR - scalar branches instead of exec-mask
+         * regions - was slower: +1.2 % on reference scene 0, profiles/r04/experiments/small_instruction_savings.txt) */
         ob.type = (int32_t)__float_as_uint(ob0.x); ob.prim_start = (int32_t)__float_as_uint(ob0.y);
         ob.need_uv = (int32_t)__float_as_uint(ob0.z); ob.root_ref = __float_as_uint(ob0.w);
         ob.v[0] = ob1.x; ob.v[1] = ob1.y; ob.v[2] = ob1.z; ob.v[3] = ob1.w;

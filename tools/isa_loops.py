@@ -3,7 +3,7 @@
    (the one holding the stack's ds_write_b64) and of the leaf loop (the one holding v_div_fixup), by instruction class."""
 import os, re, subprocess, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-flags = [a for a in sys.argv[1:] if a.startswith("-")]
+flags = [a for a in sys.argv[1:] if a.startswith("-") and a != "-v"]
 out = "/tmp/isa/rk_%s.s" % (re.sub(r"[^A-Za-z0-9]+", "_", "".join(flags)) or "base")
 os.makedirs("/tmp/isa", exist_ok=True)
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
