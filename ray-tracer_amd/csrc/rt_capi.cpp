@@ -451,7 +451,9 @@ extern "C" rt_status rt_scene_commit(rt_ctx *ctx, const rt_scene_builder *b, rt_
          * LDS holds only the traversal stacks */
         s->scene_in_lds = RT_SCENE_GLOBAL;
         s->threads = s->flat.has_mesh ? 1024 : 256;
-        if (s->flat.has_mesh) { const char *gt = getenv("RT_AMD_GLOBAL_THREADS"); if (gt && atoi(gt) == 256) s->threads = 256; }   /* development: 5 x 256 instead of 1 x 1024 */
+        /* (five or six waves per SIMD as 5-6 x 256 threads were measured on the 50,880- and 6,000-triangle scenes: 80.3 / 80.2 against
+         * 80.6 Msamples/s and 57.4 / 57.5 against 57.5 - the path is bound by the L1's address processing, not by latency:
+         * profiles/r04/experiments/big_mesh_global_5_waves.txt, pmc_vmem_sphere50k.txt) */
         s->lds_bytes = per_thread * (size_t)s->threads;
         if (s->lds_bytes > RT_LDS_LIMIT) {
             delete s;

@@ -497,7 +497,6 @@ extern "C" int rt_kernel_blocks_per_cu(int has_mesh, int scene_in_lds, int threa
 {
     if (scene_in_lds == RT_SCENE_GLOBAL) {
         if (has_mesh && threads == 1024) return rt_blocks_one<1024, true, RT_SCENE_GLOBAL>(lds_bytes);
-        if (has_mesh && threads == 256) return rt_blocks_one<256, true, RT_SCENE_GLOBAL>(lds_bytes);
         if (!has_mesh && threads == 256) return rt_blocks_one<256, false, RT_SCENE_GLOBAL>(lds_bytes);
         return 0;
     }
@@ -531,7 +530,6 @@ extern "C" hipError_t rt_launch_render(const rt_kernel_args *args, int has_mesh,
     if (scene_in_lds == RT_SCENE_GLOBAL) {
         /* global-memory scene: one shape per mesh flag is enough */
         if (has_mesh && threads == 1024) rt_launch_one<1024, true, RT_SCENE_GLOBAL>(args, blocks, lds_bytes, stream);
-        else if (has_mesh && threads == 256) rt_launch_one<256, true, RT_SCENE_GLOBAL>(args, blocks, lds_bytes, stream);
         else if (!has_mesh && threads == 256) rt_launch_one<256, false, RT_SCENE_GLOBAL>(args, blocks, lds_bytes, stream);
         else return hipErrorInvalidValue;
         return hipGetLastError();
