@@ -12,7 +12,12 @@ for r in range(rounds):
         for kv in s.split():
             k, v = kv.split("=", 1)
             env[k] = v
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "profile_run.py"), scene, spp, "1920", "1080", frames], env=env, capture_output=True, text=True, timeout=600)
+        try:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "profile_run.py"), scene, spp, "1920", "1080", frames], env=env, capture_output=True, text=True, timeout=int(os.environ.get("RT_SWEEP_TIMEOUT", "600")))
+        except subprocess.TimeoutExpired:
+            print("TIMEOUT", s, flush=True)
+            continue
+        print("  .. %s: %s" % (s or "(default)", (out.stdout.strip().splitlines() or ["?"])[-1][-40:]), flush=True)
         m = re.search(r"launch: ([0-9.]+) ms", out.stdout)
         if not m:
             print("FAILED", s, out.stdout[-300:], out.stderr[-600:], flush=True)
