@@ -324,6 +324,10 @@ rt_status rt_debug_flatten(rt_scene_builder *b, rt_flat_view *out);
  * 5 rt_u01, 6 rt_jitter, 7 rt_theta (5-7 take the uint32 hash output), 8 sqrtf, 9 1.0f/x,
  * 10 (float)rt_pow5 */
 rt_status rt_debug_eval(rt_ctx *ctx, int32_t op, const uint32_t *in, uint32_t *out, int32_t n);
+/* test hook: the device code's short 1 / x and sqrt(x) against the compiler's IEEE expansions for all 2^32 inputs; out4 = {differing
+ * inputs inside the reciprocal's range, inputs inside it, the same two for the square root}.  (The reference divides and takes roots
+ * with CUDA's IEEE operators, src/utils.cu:118-128, src/objects.cu:40-79,135-163; the short forms are the same function there.) */
+rt_status rt_debug_exhaustive(rt_ctx *ctx, unsigned long long *out4);
 /* 48 section counters / timers of a development build compiled with -DRT_STATS (all zero otherwise) */
 rt_status rt_debug_read_stats(rt_ctx *ctx, unsigned long long *out48);
 

@@ -80,7 +80,7 @@ ABI_SYMBOLS = [
     "rt_scene_get_info", "rt_render", "rt_render_frames", "rt_render_device", "rt_render_device_batch", "rt_tile_owned_rows", "rt_last_kernel_ms",
     "rt_tile_costs", "rt_partition_tiles", "rt_tiles_copy_device", "rt_max_batch_frames", "rt_peer_access",
     "rt_ctx_synchronize", "rt_render_multi", "rt_render_multi_device", "rt_gather",
-    "rt_to_rgba8_device", "rt_debug_flatten", "rt_debug_read_stats", "rt_debug_eval", "rt_version",
+    "rt_to_rgba8_device", "rt_debug_flatten", "rt_debug_read_stats", "rt_debug_eval", "rt_debug_exhaustive", "rt_version",
 ]
 
 _lib = None
@@ -186,6 +186,8 @@ def lib():
     L.rt_debug_flatten.argtypes = [vp, C.POINTER(rt_flat_view)]
     L.rt_debug_read_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rt_debug_eval.argtypes = [vp, C.c_int32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int32]
+    if hasattr(L, "rt_debug_exhaustive"):        # (absent from development builds of older revisions: tools/build_variants.py name@REV)
+        L.rt_debug_exhaustive.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.rt_version.restype = C.c_char_p
     _lib = L
     return L
@@ -742,6 +744,13 @@ def debug_eval(ctx, op, bits):
     out = np.empty_like(a)
     ctx._check(lib().rt_debug_eval(ctx._h, int(op), a.ctypes.data_as(C.POINTER(C.c_uint32)), out.ctypes.data_as(C.POINTER(C.c_uint32)), a.size))
     return out
+
+
+def debug_exhaustive(ctx):
+    """(differing, in range) for the device code's short reciprocal, then for its short square root, over all 2^32 inputs"""
+    out = (C.c_uint64 * 4)()
+    ctx._check(lib().rt_debug_exhaustive(ctx._h, out))
+    return tuple(int(x) for x in out)
 
 
 def tile_owned_rows(height, band_rows=8, band_first=0, band_stride=1):

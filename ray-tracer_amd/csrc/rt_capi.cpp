@@ -1006,7 +1006,7 @@ extern "C" rt_status rt_tiles_copy_device(rt_ctx *ctx, float *d_compact, float *
  * and returned as raw 32-bit patterns in host memory */
 extern "C" rt_status rt_debug_eval(rt_ctx *ctx, int32_t op, const uint32_t *in, uint32_t *out, int32_t n)
 {
-    if (!ctx || !in || !out || n <= 0 || op < 0 || op > 10) return set_err(ctx, RT_ERR_INVALID, "bad argument");
+    if (!ctx || !in || !out || n <= 0 || op < 0 || op > 12) return set_err(ctx, RT_ERR_INVALID, "bad argument");
     RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
     uint32_t *d_in = nullptr, *d_out = nullptr;
     RT_HIP(ctx, hipMalloc((void **)&d_in, (size_t)n * 4), "allocating eval input");
@@ -1018,6 +1018,25 @@ extern "C" rt_status rt_debug_eval(rt_ctx *ctx, int32_t op, const uint32_t *in, 
     (void)hipFree(d_in);
     if (d_out) (void)hipFree(d_out);
     if (e != hipSuccess) return hip_fail(ctx, e, "evaluating on the device");
+    return RT_OK;
+}
+
+/* test hook: the short reciprocal and square root of the device code (rt_pixel.h rt_rcp_short / rt_sqrt_short) against the
+ * compiler's IEEE expansions for every one of the 2^32 binary32 inputs, on the device.  out4 = {reciprocal: inputs inside its
+ * range that differ, inputs inside its range; square root: likewise} */
+extern "C" hipError_t rt_launch_exhaustive(unsigned long long *out4, hipStream_t stream);
+extern "C" rt_status rt_debug_exhaustive(rt_ctx *ctx, unsigned long long *out4)
+{
+    if (!ctx || !out4) return set_err(ctx, RT_ERR_INVALID, "bad argument");
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    unsigned long long *d = nullptr;
+    RT_HIP(ctx, hipMalloc((void **)&d, 32), "allocating counters");
+    hipError_t e = hipMemset(d, 0, 32);
+    if (e == hipSuccess) e = rt_launch_exhaustive(d, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out4, d, 32, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hip_fail(ctx, e, "exhaustive check on the device");
     return RT_OK;
 }
 

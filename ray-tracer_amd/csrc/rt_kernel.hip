@@ -470,9 +470,34 @@ __global__ void rt_eval_kernel(int op, const uint32_t *in, uint32_t *out, int n)
         case 8: r = sqrtf(x); break;                 /* the IEEE operations parity relies on */
         case 9: r = 1.0f / x; break;
         case 10: r = (float)rt_pow5((double)x); break;
+        case 11: r = rt_rcp_in_range(x) ? rt_rcp_short(x) : 1.0f / x; break;       /* per lane what rt_rcp / rt_sqrt do per wave */
+        case 12: r = rt_sqrt_in_range(x) ? rt_sqrt_short(x) : sqrtf(x); break;
         default: break;
     }
     out[i] = __float_as_uint(r);
+}
+
+/* rt_rcp_short / rt_sqrt_short against the compiler's IEEE expansions for ALL 2^32 inputs (tests/test_gpu_math.py): out[0] = inputs in
+ * rt_rcp's range whose short form differs from 1.0f / x, out[1] = inputs in the range, out[2], out[3] the same for the square root */
+__global__ void rt_exhaustive_kernel(unsigned long long *out)
+{
+    const uint32_t lo = blockIdx.x * 1024u + threadIdx.x;
+    unsigned bad_r = 0, in_r = 0, bad_s = 0, in_s = 0;
+    for (uint32_t hi = 0; hi < 16; hi++) {
+        const float x = __uint_as_float(lo | (hi << 28));
+        if (rt_rcp_in_range(x)) { in_r++; bad_r += __float_as_uint(rt_rcp_short(x)) != __float_as_uint(1.0f / x); }
+        if (rt_sqrt_in_range(x)) { in_s++; bad_s += __float_as_uint(rt_sqrt_short(x)) != __float_as_uint(sqrtf(x)); }
+    }
+    if (bad_r) atomicAdd(&out[0], (unsigned long long)bad_r);
+    atomicAdd(&out[1], (unsigned long long)in_r);
+    if (bad_s) atomicAdd(&out[2], (unsigned long long)bad_s);
+    atomicAdd(&out[3], (unsigned long long)in_s);
+}
+
+extern "C" hipError_t rt_launch_exhaustive(unsigned long long *out4, hipStream_t stream)
+{
+    hipLaunchKernelGGL(rt_exhaustive_kernel, dim3(1u << 18), dim3(1024), 0, stream, out4);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t rt_launch_eval(int op, const uint32_t *in, uint32_t *out, int n, hipStream_t stream)

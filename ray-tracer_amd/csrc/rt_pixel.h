@@ -21,6 +21,44 @@
  * (a struct of four floats gets split into narrower loads by the optimiser) */
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+/* ---- 1 / x and sqrt(x), correctly rounded, in a third of the instructions (round 4) ---------------------------------
+ * The compiler expands `1.0f / x` into 11 instructions (v_div_scale x 2, v_rcp, five fma, v_div_fmas, v_div_fixup) and sqrtf
+ * into 17 + 5 s_nop, most of it for inputs a renderer never sees: denormals, results that underflow, zero, infinity.  On gfx950
+ *   v_rcp_f32 + one Newton step (two fma)                is 1.0f / x bit for bit for every x with 2^-126 <= |x| <= 2^126,
+ *   v_sqrt_f32 + the -1 / +1 ulp residual test (2 fma)   is sqrtf(x) bit for bit for every x with 2^-64 <= x < inf,
+ * checked EXHAUSTIVELY - all 2^32 inputs against the compiler's expansions on the device, tests/test_gpu_math.py
+ * (tools/ubench/exact_div_sqrt.hip, profiles/r04/experiments/exact_div_sqrt.txt: outside those ranges every single input fails,
+ * inside none).  rt_sqrt / rt_rcp_sqrt take the short forms when EVERY active lane's operand is inside the range (one subtract,
+ * one compare, a wave-uniform branch) and the compiler's otherwise: the value is the IEEE one for every input, always.  Used
+ * where it pays: the normalisations (1 / sqrt: 41 -> 24 instructions), the sphere test's and Box-Muller's roots; same-box A/B:
+ * three-sphere -8 %, cube -3.6 %, reference scene 0 -0.9 %, monkey -0.3 % (profiles/r04/experiments/exact_div_sqrt_ab.txt). */
+__device__ __forceinline__ bool rt_rcp_in_range(float x) { return ((__float_as_uint(x) & 0x7fffffffu) - 0x00800000u) <= 0x7e000000u; }
+__device__ __forceinline__ bool rt_sqrt_in_range(float x) { return (__float_as_uint(x) - 0x1f800000u) < 0x60000000u; }
+__device__ __forceinline__ float rt_rcp_short(float x)
+{
+    const float y = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(y, __builtin_fmaf(-x, y, 1.0f), y);
+}
+__device__ __forceinline__ float rt_sqrt_short(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rdn = __builtin_fmaf(-dn, s, x), rup = __builtin_fmaf(-up, s, x);
+    s = rdn <= 0.0f ? dn : s;
+    return rup > 0.0f ? up : s;
+}
+__device__ __forceinline__ float rt_sqrt(float x)       /* == sqrtf(x) */
+{
+    if (__ballot(!rt_sqrt_in_range(x)) == 0ull) return rt_sqrt_short(x);
+    return sqrtf(x);
+}
+/* 1.0f / sqrtf(m): sqrt of an in-range m lies in [2^-32, 2^64], inside the reciprocal's range - one check for both */
+__device__ __forceinline__ float rt_rcp_sqrt(float m)
+{
+    if (__ballot(!rt_sqrt_in_range(m)) == 0ull) return rt_rcp_short(rt_sqrt_short(m));
+    return 1.0f / sqrtf(m);
+}
+
 struct V3 { float x, y, z; };
 
 __device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -37,7 +75,7 @@ __device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.
 __device__ __forceinline__ V3 normalised(V3 a)
 {
     float m = a.x * a.x + a.y * a.y + a.z * a.z;
-    float inv = 1.0f / sqrtf(m);
+    float inv = rt_rcp_sqrt(m);
     return v3(a.x * inv, a.y * inv, a.z * inv);
 }
 __device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
@@ -48,7 +86,7 @@ __device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ float normal_num(uint32_t &state)
 {
     float theta = rt_theta(rt_pcg_next(&state));
-    float rho = sqrtf(-2.0f * rt_logf(rt_u01(rt_pcg_next(&state))));
+    float rho = rt_sqrt(-2.0f * rt_logf(rt_u01(rt_pcg_next(&state))));
     return rho * rt_cosf(theta);
 }
 
@@ -165,7 +203,7 @@ __device__ __forceinline__ unsigned long long tri_closer_lanes(const v4f *tris, 
     V3 p0 = v3(q0.x, q0.y, q0.z), s1 = v3(q0.w, q1.x, q1.y), s2 = v3(q1.z, q1.w, q2.x);
     V3 p_vec = cross(d, s2);
     float det = dot(s1, p_vec);
-    float inv_det = 1.0f / det;
+    float inv_det = 1.0f / det;        /* (the short reciprocal behind a range check is 3 % SLOWER here: the check and its branch sit in the leaf loop) */
     V3 t_vec = o - p0;
     u = dot(t_vec, p_vec) * inv_det;
     V3 q_vec = cross(t_vec, s1);
@@ -572,7 +610,7 @@ __device__ __forceinline__ void px_gen(Px &p, const rt_kernel_args &a, const Lds
         off.z = rt_jitter(rt_pcg_next(&p.rng));
         d = normalised(d + off);
     }
-    if (HAS_MESH) p.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   /* src/ray.cu:198-202 */
+    if (HAS_MESH) p.inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   /* src/ray.cu:198-202 (three short reciprocals behind one range check: -0.3 % cube, +0.5 % monkey - not taken) */
 
     /* get_ray_collision src/raytracer.cu:24-46 over the non-mesh objects, in list order
      * (`<=`: the later object wins ties, :36; the precision_error term is a no-op for
@@ -601,7 +639,7 @@ __device__ __forceinline__ void px_gen(Px &p, const rt_kernel_args &a, const Lds
                 float qc = dot(cq, cq) - ob.v[3] * ob.v[3];
                 float disc = qb * qb - 4.0f * qa * qc;
                 if (disc >= 0.0f) {
-                    float dist = (-qb - sqrtf(disc)) / (2.0f * qa);
+                    float dist = (-qb - rt_sqrt(disc)) / (2.0f * qa);
                     if (dist > RT_EPS_F) { hit = true; t = dist; }
                 }
                 break;

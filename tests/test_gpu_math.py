@@ -65,3 +65,32 @@ def test_device_equals_host(rt, ctx, host_eval, op, name, gen):
     assert np.array_equal(dev_nan, host_nan)
     mism = (dev != host) & ~dev_nan
     assert not mism.any(), "%s: %d of %d differ, first input 0x%08x" % (name, int(mism.sum()), bits.size, int(bits[np.argmax(mism)]))
+
+
+def test_short_reciprocal_and_square_root_are_the_ieee_ones_for_all_inputs(rt, ctx):
+    """rt_pixel.h computes 1 / x as v_rcp_f32 + one Newton step and sqrt(x) as v_sqrt_f32 + a +-1 ulp residual test whenever every
+    lane's operand is inside the range those short forms are exact on (2^-126 <= |x| <= 2^126; 2^-64 <= x < inf), and as the
+    compiler's IEEE expansion otherwise.  "Exact" is checked here for EVERY binary32 input on the device: inside the ranges
+    not one of the 4.2e9 (reciprocal) and 1.6e9 (square root) inputs may differ from 1.0f / x and sqrtf(x)."""
+    bad_r, in_r, bad_s, in_s = rt.debug_exhaustive(ctx)
+    assert in_r == 2 * (0x7e800000 - 0x00800000 + 1)           # both signs, 2^-126 .. 2^126 inclusive
+    assert in_s == 0x7f800000 - 0x1f800000                      # 2^-64 .. the largest finite float
+    assert bad_r == 0 and bad_s == 0, (bad_r, bad_s)
+
+
+def test_guarded_forms_equal_the_operators_outside_the_ranges_too(rt, ctx):
+    """per lane what rt_rcp / rt_sqrt decide per wave (short form in range, the operator outside): specials, denormals, huge and
+    tiny values, negative arguments of the root"""
+    rng = np.random.default_rng(9)
+    bits = np.concatenate([rng.integers(0, 2**32, 200000, dtype=np.uint64).astype(np.uint32),
+                           np.array([0, 0x80000000, 1, 0x007fffff, 0x00800000, 0x7e800000, 0x7e800001, 0x7f7fffff, 0x7f800000, 0xff800000, 0x7fc00000,
+                                     0x1f7fffff, 0x1f800000, 0x3f800000, 0xbf800000], np.uint32)])
+    with np.errstate(all="ignore"):
+        x = bits.view(np.float32)
+        want_r = (np.float32(1.0) / x).view(np.uint32)
+        want_s = np.sqrt(x).view(np.uint32)
+    got_r = rt.debug_eval(ctx, 11, bits)
+    got_s = rt.debug_eval(ctx, 12, bits)
+    nan = lambda u: (u & 0x7fffffff) > 0x7f800000
+    assert np.array_equal(np.where(nan(got_r), 0x7fc00000, got_r), np.where(nan(want_r), 0x7fc00000, want_r))
+    assert np.array_equal(np.where(nan(got_s), 0x7fc00000, got_s), np.where(nan(want_s), 0x7fc00000, want_s))

