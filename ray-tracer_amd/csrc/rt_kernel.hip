@@ -47,6 +47,10 @@
 
 #include "rt_pixel.h"
 
+/* LLVM integer-compare predicates for __builtin_amdgcn_uicmp / sicmp (lane mask of a compare, straight into an SGPR pair) */
+#define RT_ICMP_EQ 32
+#define RT_ICMP_SGE 39
+
 /* Development instrumentation (-DRT_STATS, tools/stats_run.py): per code section, how many
  * times a wave executed it and with how many active lanes.  Compiled out of the product. */
 #ifdef RT_STATS
@@ -138,15 +142,20 @@ __device__ __forceinline__ void rt_descend(uint32_t &cur, int &sp, uint2 *my_sta
         const uint32_t next = both ? (l_first ? rref : lref) : (l_push ? lref : rref);
         cur = entered ? next : RT_REF_EMPTY_LEAF;
         {
-            /* one divergent exit instead of a divergent and a wave-uniform one: the count of lanes still descending goes
-             * through a VGPR, so the compiler folds "fewer than n_keep remain" into the lane's own exit condition
-             * (7 scalar instructions and a branch per node step instead of 16 and 3: -2 % on the monkey,
-             * profiles/r04/experiments/keep_rule_single_exit.txt) */
-            const bool leaf = (int)cur < 0;
-            const int c = __popcll(__ballot(1)) - __popcll(__ballot(leaf));
-            int cv;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(cv) : "s"(c));
-            if (leaf || cv < n_keep) break;
+            /* One divergent exit: the lanes that leave - those that reached a leaf, or everybody once fewer than n_keep are
+             * still on an internal node - are computed as a lane mask in five instructions (one compare, four scalar) and handed
+             * to the compiler as the loop's exit condition (inverse ballot: no instruction).  The compiler's own rendering of
+             * "leaf || count < n_keep" took 16 scalar instructions and 3 branches per node step (round 3), then, with the count
+             * passed through a VGPR, 9 + 3 vector ones (-2 %, profiles/r04/experiments/keep_rule_single_exit.txt). */
+            unsigned long long stop, internal;
+            int cnt;
+            asm volatile("v_cmp_gt_i32_e64 %0, 0, %3\n\t"
+                         "s_andn2_b64 %1, exec, %0\n\t"
+                         "s_bcnt1_i32_b64 %2, %1\n\t"
+                         "s_cmp_lt_u32 %2, %4\n\t"
+                         "s_cselect_b64 %0, exec, %0"
+                         : "=&s"(stop), "=&s"(internal), "=&s"(cnt) : "v"(cur), "s"(n_keep) : "scc");
+            if (__builtin_amdgcn_inverse_ballot_w64(stop)) break;
         }
     }
 }
@@ -272,13 +281,17 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : (HAS_MESH ? RT_SMALL_WG_WAVES 
              * every comparison are the reference's. */
             const V3 o = p.o, d = p.d, inv = p.inv;
             for (;;) {
-                const int n_active = __popcll(__ballot(p.mode == M_WAIT));
+                /* the three lane counts from four compare masks combined in scalar registers (a __ballot of a bool built from
+                 * several compares is rebuilt through a v_cndmask and a v_cmp) */
+                const unsigned long long m_wait = __builtin_amdgcn_uicmp((unsigned)p.mode, (unsigned)M_WAIT, RT_ICMP_EQ);
+                const int n_active = __popcll(m_wait);
                 if (n_active == 0) break;
                 /* lanes holding a hit wait for a batch of `hit_break`; the cheap kinds of ready
                  * lane (generate, fetch, next mesh, a miss) for one of `ready_break` */
-                const bool is_hit = p.mode == M_SHADE && p.best_obj >= 0;
-                const int n_hit = __popcll(__ballot(is_hit));
-                const int n_light = __popcll(__ballot(p.mode != M_WAIT && p.mode != M_DONE && !is_hit));
+                const unsigned long long m_hit = __builtin_amdgcn_uicmp((unsigned)p.mode, (unsigned)M_SHADE, RT_ICMP_EQ) & __builtin_amdgcn_sicmp(p.best_obj, 0, RT_ICMP_SGE);
+                const unsigned long long m_done = __builtin_amdgcn_uicmp((unsigned)p.mode, (unsigned)M_DONE, RT_ICMP_EQ);
+                const int n_hit = __popcll(m_hit);
+                const int n_light = __popcll(__ballot(1) & ~(m_wait | m_done | m_hit));
                 /* ... or a smaller batch of hits that, together with the cheap-work lanes, is worth the round: where
                  * every traversal ends in a hit (a closed scene) hits fill a big batch fast and big batches are what
                  * the 700-instruction shade wants; where most rays escape (an open scene) hits are rare, the lanes

@@ -288,6 +288,33 @@ def test_tile_list_cache_recycles_entries(rt):
         assert np.array_equal(frame.cpu().numpy(), want), k
 
 
+def test_preview_quality_costs_are_measured_again(rt):
+    """a view's tile costs used to be measured once - a first launch at 1 sample per pixel (a preview, a profiler's warm-up)
+    then fixed the schedule and the GPU ownership of every later launch.  Now figures from a launch with an eighth of the samples or
+    fewer are provisional: the next full launch collects again, and the bounce limit is part of the view's key."""
+    import torch
+    objs, sky = rt.scenes.monkey()
+    W, H = 160, 96
+    ctx = rt.Context(0)
+    scene = ctx.commit(rt.SceneObjects(objs))
+    cam = rt.Camera(W, H)
+    out = torch.zeros((H, W, 3), device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    rt.render_device(ctx, scene, cam, rt.RenderData(1, 8, True, sky), 5, 0, out.data_ptr(), stream=st)
+    ids1, c1 = ctx.tile_costs()
+    rt.render_device(ctx, scene, cam, rt.RenderData(64, 8, True, sky), 5, 0, out.data_ptr(), stream=st)    # runs on the 1-spp figures, measures again
+    ids2, c2 = ctx.tile_costs()
+    assert np.array_equal(ids1, ids2)
+    heavy = (c1 >> 1) > 0
+    assert ((c2 >> 1)[heavy] > 8 * (c1 >> 1)[heavy]).mean() > 0.9          # 64 samples' worth of work, not 1
+    rt.render_device(ctx, scene, cam, rt.RenderData(64, 8, True, sky), 6, 0, out.data_ptr(), stream=st)    # same quality: the figures stand
+    _, c3 = ctx.tile_costs()
+    assert np.array_equal(c2, c3)
+    rt.render_device(ctx, scene, cam, rt.RenderData(64, 2, True, sky), 6, 0, out.data_ptr(), stream=st)    # another bounce limit: another view
+    _, c4 = ctx.tile_costs()
+    assert not np.array_equal(c3, c4) and (c4 >> 1).sum() < (c3 >> 1).sum()
+
+
 def test_render_multi_argument_errors(rt):
     objs, sky = rt.scenes.three_sphere()
     a, b = rt.Context(0), rt.Context(0)

@@ -1,9 +1,9 @@
 set -o pipefail
 export TMPDIR=/tmp
-O=gpurun_out/r03m
+O=gpurun_out/r04m
 mkdir -p $O
 timeout -k 10 400 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest exit=$?"; tail -2 $O/pytest.log
-NO_CONFIG4= bash tools/profile_all.sh r03 monkey three_sphere cube reference_scene0 sphere50k > $O/profile_all.log 2>&1; echo "profile_all exit=$?"; grep "exit=" $O/profile_all.log | tr '\n' ' '
+NO_CONFIG4= bash tools/profile_all.sh r04 monkey three_sphere cube reference_scene0 sphere50k > $O/profile_all.log 2>&1; echo "profile_all exit=$?"; grep "exit=" $O/profile_all.log | tr '\n' ' '
 for s in monkey three_sphere cube; do RT_AMD_LIB=/root/repo/ray-tracer_amd/libraytracer_amd_stats.so timeout -k 10 120 python tools/stats_run.py $s 256 8 > $O/section_stats_${s}_f8.txt 2>&1; done; echo stats done
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_config3_driver.json 2> $O/bench_config3_driver.err; echo "bench3 exit=$?"
 timeout -k 10 300 python bench.py > $O/bench_default.json 2>/dev/null; echo "bench default exit=$?"

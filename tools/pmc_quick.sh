@@ -11,8 +11,10 @@ python3 - <<PY
 import csv, glob, collections
 t = collections.defaultdict(float)
 for f in glob.glob("$OUT/p*/*/*_counter_collection.csv"):
-    for row in csv.DictReader(open(f)):
-        if "rt_render_kernel" in row["Kernel_Name"]:
+    rows = [row for row in csv.DictReader(open(f)) if "rt_render_kernel" in row["Kernel_Name"]]
+    last = max(int(row["Dispatch_Id"]) for row in rows) if rows else -1        # (the launch before it is tools/profile_run.py's cost-collecting one)
+    for row in rows:
+        if int(row["Dispatch_Id"]) == last:
             t[row["Counter_Name"]] += float(row["Counter_Value"])
 print("$TAG", open("$OUT/p1.log").read().strip().splitlines()[-1])
 print("  waves %d  VALU insts/wave %.3g  SALU/wave %.3g  LDS/wave %.3g" % (t["SQ_WAVES"], t["SQ_INSTS_VALU"]/t["SQ_WAVES"], t["SQ_INSTS_SALU"]/t["SQ_WAVES"], t["SQ_INSTS_LDS"]/t["SQ_WAVES"]))

@@ -23,8 +23,10 @@ python3 - <<PY
 import csv, glob, collections
 t = collections.defaultdict(float)
 for f in glob.glob("$OUT/p*/*/*_counter_collection.csv"):
-    for row in csv.DictReader(open(f)):
-        if "rt_render_kernel" in row["Kernel_Name"]:
+    rows = [row for row in csv.DictReader(open(f)) if "rt_render_kernel" in row["Kernel_Name"]]
+    last = max(int(row["Dispatch_Id"]) for row in rows) if rows else -1        # (the launch before it is tools/profile_run.py's cost-collecting one)
+    for row in rows:
+        if int(row["Dispatch_Id"]) == last:
             t[row["Counter_Name"]] += float(row["Counter_Value"])
 for k in sorted(t): print("%-40s %.6g" % (k, t[k]))
 PY

@@ -15,9 +15,11 @@ ctx = rt.Context(0)
 scene = ctx.commit(rt.SceneObjects(objs))
 out = torch.empty((H, W, 3), device="cuda:0")
 st = torch.cuda.current_stream().cuda_stream
-# the first launch of a view also measures tile costs (one atomic per pixel per frame): get that out
-# of the way with a 1-spp launch, whose counters are ~1/spp of the profiled launch's
-rt.render_device(ctx, scene, rt.Camera(W, H), rt.RenderData(1, 8, True, sky), 12345, 0, out.data_ptr(), stream=st)
+# the first launch of a view also measures tile costs (atomics per pixel): get that out of the way with one frame at the
+# SAME sample count - figures from a launch with an eighth of the samples or fewer are provisional and the next launch
+# would measure again (rt_capi.cpp), which is not the kind of launch bench.py times.  The summaries (tools/summarize_profile.py,
+# tools/fit_traffic.py, tools/pmc_bound.sh) read the LAST dispatch of the kernel only.
+rt.render_device(ctx, scene, rt.Camera(W, H), rt.RenderData(spp, 8, True, sky), 12345, 0, out.data_ptr(), stream=st)
 torch.cuda.synchronize()
 if frames > 1:
     rt.render_device_batch(ctx, scene, rt.Camera(W, H), rt.RenderData(spp, 8, True, sky), [12345 + i for i in range(frames)], 0, out.data_ptr(), stream=st)
