@@ -49,6 +49,7 @@
 
 /* LLVM integer-compare predicates for __builtin_amdgcn_uicmp / sicmp (lane mask of a compare, straight into an SGPR pair) */
 #define RT_ICMP_EQ 32
+#define RT_ICMP_NE 33
 #define RT_ICMP_SGE 39
 
 /* Development instrumentation (-DRT_STATS, tools/stats_run.py): per code section, how many
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : (HAS_MESH ? RT_SMALL_WG_WAVES 
     uint32_t cur = 0;
     int sp = 0, w_prim = -1;
     float w_best = RT_INF_F;
-    bool w_zero_dir = false;     /* this traversal's ray has a direction component of exactly zero (box_enter_med3) */
+    uint32_t w_zero_dir = 0u;    /* this traversal's ray has a direction component of exactly zero (box_enter_med3); an integer: its lane mask is then one compare */
     Chunk ch;
     ch.next = 0; ch.end = 0; ch.frame = 0; ch.exhausted = false;
 #ifdef RT_STATS
@@ -232,9 +233,10 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : (HAS_MESH ? RT_SMALL_WG_WAVES 
          * traversal loop below already yields in batches (`ready_break`). */
         if (p.mode == M_SHADE && p.best_obj < 0) px_shade_miss(p, a, f);
         {
-            const int n_hit = __popcll(__ballot(p.mode == M_SHADE));
-            const bool others = __ballot(p.mode == M_GEN || (p.mode == M_FETCH && !ch.exhausted)) != 0ull;
-            const int n_trav = __popcll(__ballot(p.mode == M_WAIT));
+            const int n_hit = __popcll(__builtin_amdgcn_uicmp((unsigned)p.mode, (unsigned)M_SHADE, RT_ICMP_EQ));
+            const bool others = (__builtin_amdgcn_uicmp((unsigned)p.mode, (unsigned)M_GEN, RT_ICMP_EQ) |
+                                 (ch.exhausted ? 0ull : __builtin_amdgcn_uicmp((unsigned)p.mode, (unsigned)M_FETCH, RT_ICMP_EQ))) != 0ull;
+            const int n_trav = __popcll(__builtin_amdgcn_uicmp((unsigned)p.mode, (unsigned)M_WAIT, RT_ICMP_EQ));
             if (n_hit > 0 && (HAS_MESH ? (n_hit >= a.hit_low || n_trav < a.work_threshold)
                                         : (n_hit >= a.shade_batch || !others))) {
                 if (p.mode == M_SHADE) {
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : (HAS_MESH ? RT_SMALL_WG_WAVES 
                 const bool rh = box_test(m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, p.o, p.inv, rd);
                 if (!rh || rd > RT_INF_F || ((root_ref & RT_REF_CHAIN) && !(rd < RT_INF_F))) continue;
                 cur = root_ref; sp = 0; w_best = RT_INF_F; w_prim = -1;
-                w_zero_dir = p.d.x == 0.0f || p.d.y == 0.0f || p.d.z == 0.0f;
+                w_zero_dir = (p.d.x == 0.0f || p.d.y == 0.0f || p.d.z == 0.0f) ? 1u : 0u;
                 p.mode = M_WAIT;
                 p.frame_steps |= 0x80000000u;           /* (cost bookkeeping: this pixel traverses) */
                 RT_STAT(ST_MESH_START);
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : (HAS_MESH ? RT_SMALL_WG_WAVES 
                     if (!(cur & RT_REF_LEAF)) {
                         /* two copies of the loop: the six-med3 slab test where no traversing ray of the wave has a direction
                          * component of exactly zero (always, in practice), the reference's min / max form otherwise */
-                        if (__ballot(w_zero_dir) == 0ull) rt_descend<NT, true>(cur, sp, my_stack, L, o, inv, w_best, a.descend_keep RT_STAT_ARGS);
+                        if (__builtin_amdgcn_uicmp(w_zero_dir, 0u, RT_ICMP_NE) == 0ull) rt_descend<NT, true>(cur, sp, my_stack, L, o, inv, w_best, a.descend_keep RT_STAT_ARGS);
                         else rt_descend<NT, false>(cur, sp, my_stack, L, o, inv, w_best, a.descend_keep RT_STAT_ARGS);
                     }
                     RT_LAP_SPLIT(TM_DESCEND)
