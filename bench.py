@@ -449,7 +449,7 @@ def main():
     capi_after_group = capi_runs_after_group(bool(capi_devices), world, backend, host_group is not None)
     if capi_devices and not capi_after_group:
         if rank == 0:
-            extras["capi_multi"] = capi_multi(args, capi_devices, W, H, spp, limit, frame if batched else None)
+            extras["capi_multi"] = capi_multi_with_fallback(args, capi_devices, W, H, spp, limit, frame if batched else None)
         if world > 1:
             dist.barrier(group=host_group)          # gloo: the waiting ranks sleep in a socket, their GPUs are the child's
 
@@ -512,7 +512,7 @@ def main():
         frame_ref = frame if batched else None
         dist.destroy_process_group()
         if rank == 0:
-            extras["capi_multi"] = capi_multi(args, capi_devices, W, H, spp, limit, frame_ref)
+            extras["capi_multi"] = capi_multi_with_fallback(args, capi_devices, W, H, spp, limit, frame_ref)
             extras["capi_multi"]["ran"] = "after destroy_process_group (no gloo side group to wait in)"
     if extras:
         out["extras"] = extras
@@ -615,6 +615,23 @@ def capi_multi(args, devices, W, H, spp, limit, reference_frame, timeout_s=300, 
     if reference_frame is not None:
         out["equals_gathered_frame"] = out.pop("frame_sha256") == hashlib.sha256(reference_frame.contiguous().cpu().numpy().tobytes()).hexdigest()
     return out
+
+
+def capi_multi_with_fallback(args, devices, W, H, spp, limit, reference_frame):
+    """capi_multi; if the asynchronous form fails, hangs or renders another frame than the gathered one, once more with
+    RT_AMD_MULTI_CAREFUL=1 (the host waits after every phase of rt_render_multi_device, no ordering between devices rests on an
+    event): the pair of outcomes says whether a fault is in the event choreography or in the copies."""
+    first = capi_multi(args, devices, W, H, spp, limit, reference_frame)
+    if "error" not in first and first.get("equals_gathered_frame", True):
+        return first
+    os.environ["RT_AMD_MULTI_CAREFUL"] = "1"
+    try:
+        second = capi_multi(args, devices, W, H, spp, limit, reference_frame, timeout_s=240)
+    finally:
+        os.environ.pop("RT_AMD_MULTI_CAREFUL", None)
+    first["careful_mode"] = second
+    first["careful_mode"]["note"] = "RT_AMD_MULTI_CAREFUL=1: the host waits for every stream after each phase"
+    return first
 
 
 def capi_multi_child(args):

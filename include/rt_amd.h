@@ -289,6 +289,9 @@ rt_status rt_render_multi(const rt_rank *ranks, int32_t n_ranks, const rt_camera
  * the static partition of round 2 - rank i owns the bands b % n_ranks == i; band_rows == 0: cost-balanced
  * tile lists as described above.  Asynchronous: the frame is complete in the order of hip_stream (a stream of
  * ranks[0]'s GPU, NULL = default stream); rt_ctx_synchronize on each rank reports kernel errors. */
+/* (Diagnosis: with RT_AMD_MULTI_CAREFUL=1 in the environment when the ROOT context is created, the call waits on the host for
+ * every stream involved after each of its phases - scatter-out, the ranks' kernels and copies, de-interleave - and an error names
+ * the phase: same frames, no overlap.) */
 rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_ranks, const rt_camera *cam, const rt_render_settings *rs,
                                  const int32_t *times_ms, int32_t n_frames, int32_t frame_num, int32_t band_rows,
                                  float *d_frame, void *hip_stream);

@@ -137,6 +137,7 @@ struct rt_ctx {
     int hit_break = RT_DEF_HIT_BREAK;          /* lanes; RT_AMD_HIT_BREAK */
     int hit_low = RT_DEF_HIT_LOW, mix_break = RT_DEF_MIX_BREAK;   /* RT_AMD_HIT_LOW, RT_AMD_MIX_BREAK (0 = that rule off) */
     int shade_batch = RT_DEF_SHADE_BATCH;        /* lanes; RT_AMD_SHADE_BATCH (1..64) */
+    int multi_careful = 0;                       /* RT_AMD_MULTI_CAREFUL=1: rt_render_multi_device waits on the host after every phase (diagnosis) */
 };
 
 struct rt_scene {
@@ -323,6 +324,7 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (const char *e = getenv("RT_AMD_HIT_LOW")) { int v = atoi(e); if (v >= 0 && v <= 65) ctx->hit_low = v; }
     if (const char *e = getenv("RT_AMD_MIX_BREAK")) { int v = atoi(e); if (v >= 0 && v <= 130) ctx->mix_break = v; }
     if (const char *e = getenv("RT_AMD_SHADE_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->shade_batch = v; }
+    if (const char *e = getenv("RT_AMD_MULTI_CAREFUL")) ctx->multi_careful = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_READY_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->ready_break = v; }
     if (hipMalloc((void **)&ctx->tile_counter, 1024) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
@@ -1452,9 +1454,27 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
             else RT_HIP(root, copy_bands(L, i, d_frame, stage[(size_t)i]->d, false, s0), "interleaving bands");
         }
     }
+    /* RT_AMD_MULTI_CAREFUL=1 (diagnosis): the host waits for every stream involved after each phase, so that no ordering between
+     * devices rests on an event - if a frame is wrong or a call hangs in the asynchronous form but not in this one, the
+     * fault is in the event choreography, otherwise in the copies themselves; an error names the phase it was found in.
+     * bench.py's capi_multi leg falls back to it by itself (this path has never run on two physical GPUs). */
+    auto careful = [&](const char *phase) -> rt_status {
+        if (!root->multi_careful) return RT_OK;
+        for (int i = 0; i < n_ranks; i++) {
+            rt_ctx *c = ranks[i].ctx;
+            hipError_t e = hipSetDevice(c->device);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->multi_stream);
+            if (e != hipSuccess) { (void)hipSetDevice(root->device); return hip_fail(root, e, phase); }
+        }
+        hipError_t e = hipSetDevice(root->device);
+        if (e == hipSuccess) e = hipStreamSynchronize(s0);
+        if (e != hipSuccess) return hip_fail(root, e, phase);
+        return RT_OK;
+    };
     /* (frame 0 ignores the buffers' content, but the staging areas may still be read by an earlier call's
      * de-interleave: stage_for has ordered s0 behind that, and the ranks start behind s0) */
     RT_HIP(root, hipEventRecord(root->ev_multi, s0), "recording the start event");
+    if ((st = careful("careful mode: waiting for the caller's stream before the ranks start")) != RT_OK) return st;
     for (int i = 0; i < n_ranks; i++) {
         rt_ctx *c = ranks[i].ctx;
         RT_HIP(c, hipSetDevice(c->device), "selecting device");
@@ -1462,6 +1482,7 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
         if (frame_num > 0)
             RT_HIP(c, copy_between(c->d_bands, c->device, stage[(size_t)i]->d, root->device, plan[(size_t)i].floats * 4, c->multi_stream), "copying the image so far to its owner");
     }
+    if ((st = careful("careful mode: waiting for the image so far to reach its owners (scatter-out)")) != RT_OK) return st;
     /* ---- every rank renders its tiles (asynchronous launches from this one thread) and sends them back ---- */
     for (int i = 0; i < n_ranks; i++) {
         rt_ctx *c = ranks[i].ctx;
@@ -1477,6 +1498,7 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
         RT_HIP(c, copy_between(stage[(size_t)i]->d, root->device, c->d_bands, c->device, plan[(size_t)i].floats * 4, c->multi_stream), "copying the rank's image to the root GPU");
         RT_HIP(c, hipEventRecord(c->ev_multi, c->multi_stream), "recording the gather event");
     }
+    if ((st = careful("careful mode: waiting for the ranks' kernels and their copies to the root GPU")) != RT_OK) return st;
     RT_HIP(root, hipSetDevice(root->device), "selecting device");
     for (int i = 0; i < n_ranks; i++) {
         if (plan[(size_t)i].floats == 0) continue;
@@ -1486,6 +1508,7 @@ extern "C" rt_status rt_render_multi_device(const rt_rank *ranks, int32_t n_rank
         RT_HIP(root, hipEventRecord(stage[(size_t)i]->ev_free, s0), "recording the staging event");
         stage[(size_t)i]->used = true;
     }
+    if ((st = careful("careful mode: waiting for the de-interleave into the frame")) != RT_OK) return st;
     if (listed && collect_after) ms.stage = 1;
     return RT_OK;
 }

@@ -288,6 +288,37 @@ def test_tile_list_cache_recycles_entries(rt):
         assert np.array_equal(frame.cpu().numpy(), want), k
 
 
+def test_multi_device_careful_mode_renders_the_same_frames(rt, monkeypatch):
+    """RT_AMD_MULTI_CAREFUL=1 (read when the root context is created): rt_render_multi_device waits on the host after every
+    phase.  Same frames as the asynchronous form, over three calls (interleaved ownership, balanced ownership, progressive
+    frames on top)."""
+    import torch
+    objs, sky = rt.scenes.cube()
+    W, H, spp, n = 104, 72, 3, 4
+    cam, rd = rt.Camera(W, H), rt.RenderData(spp, 6, True, sky)
+    so = rt.SceneObjects(objs)
+    frames = {}
+    for careful in ("0", "1"):
+        monkeypatch.setenv("RT_AMD_MULTI_CAREFUL", careful)
+        ctxs = [rt.Context(0) for _ in range(n)]
+        scenes = [c.commit(so) for c in ctxs]
+        st = torch.cuda.current_stream().cuda_stream
+        frame = torch.zeros((H, W, 3), device="cuda:0")
+        done = 0
+        for times in ([11, 12], [13], [14, 15, 16]):
+            rt.render_multi_device(ctxs, scenes, cam, rd, times, done, frame.data_ptr(), stream=st)
+            done += len(times)
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.synchronize()
+        frames[careful] = frame.cpu().numpy()
+    assert eq(frames["0"], frames["1"])
+    single = rt.VariableRenderData(W, H)
+    ctx = rt.Context(0)
+    rt.render_frames(ctx, ctx.commit(so), cam, rd, single, [11, 12, 13, 14, 15, 16])
+    assert eq(frames["1"], single.previous_render)
+
+
 def test_preview_quality_costs_are_measured_again(rt):
     """a view's tile costs used to be measured once - a first launch at 1 sample per pixel (a preview, a profiler's warm-up)
     then fixed the schedule and the GPU ownership of every later launch.  Now figures from a launch with an eighth of the samples or
