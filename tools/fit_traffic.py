@@ -16,7 +16,9 @@ for sub in sorted(glob.glob(os.path.join(d, "hbm_*"))):
         continue
     scene, frames, kind = m.group(1) + "_" + m.group(2) + "_l8", int(m.group(3)), m.group(4)
     total, last = collections.defaultdict(float), -1
-    for f in glob.glob(os.path.join(sub, "**", "*_counter_collection.csv"), recursive=True):
+    # (a scratch directory that has seen several runs holds one file per run: the newest is this run's)
+    files = sorted(glob.glob(os.path.join(sub, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:
         rows = [r for r in csv.DictReader(open(f)) if "rt_render_kernel" in r["Kernel_Name"]]
         if not rows:
             continue
