@@ -425,6 +425,38 @@ def main():
         f_elapsed = measure(W, H, spp, limit, 0, args.steps, False)["elapsed"]
         per_frame = {"value": W * H * spp * args.steps / f_elapsed / 1e6, "unit": "Msamples/s", "ms_per_step": f_elapsed / args.steps * 1e3,
                      "frames_per_s": args.steps / f_elapsed, "note": "one launch per step (the reference's main-loop cadence, src/main.cu:415-431)"}
+    pipelined = None
+    if batched and rank == 0 and world == 1 and not args.no_frame_by_frame_leg and hasattr(rt, "frame_submit"):
+        # one launch per frame through rt_frame_submit / rt_frame_collect: seeds handed over one call at a time (the reference's loop
+        # draws them from the wall clock), the next frames submitted before the oldest is waited for, each on 1 / depth of the CUs
+        def run_pipelined(depth, n_frames):
+            pf = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+            rt.frame_depth(ctx, depth)
+            fence()
+            t0 = time.perf_counter()
+            n_done = 0
+            for i in range(n_frames):
+                if rt.frames_pending(ctx) == depth:
+                    rt.frame_collect(ctx, n_done, pf.data_ptr(), stream=stream)
+                    n_done += 1
+                    rt.frame_wait(ctx)        # the caller draws frame n_done - 1 here; the younger frames keep the GPU busy
+                rt.frame_submit(ctx, scene, cam, rd, 12345 + i)
+            while rt.frames_pending(ctx):
+                rt.frame_collect(ctx, n_done, pf.data_ptr(), stream=stream)
+                n_done += 1
+                rt.frame_wait(ctx)
+            fence()
+            el = time.perf_counter() - t0
+            return {"frames_in_flight": depth, "steps": n_frames, "value": W * H * spp * n_frames / el / 1e6, "unit": "Msamples/s",
+                    "ms_per_step": el / n_frames * 1e3, "frames_per_s": n_frames / el}, pf
+        p4, pf = run_pipelined(rt.PIPELINE_DEFAULT_DEPTH, args.steps)
+        pipelined = dict(p4)
+        pipelined["equals_batched"] = bool(frame is not None and torch.equal(pf.view(torch.int32), frame.contiguous().view(torch.int32)))
+        del pf
+        # the deepest pipeline over a run long enough to show its steady state (filling and draining it costs a frame's latency)
+        pipelined["deepest"] = run_pipelined(rt.PIPELINE_DEPTH, max(args.steps, 3 * rt.PIPELINE_DEPTH))[0]
+        pipelined["note"] = ("one launch per step through rt_frame_submit / rt_frame_collect: each seed handed over at call time, frames_in_flight submitted "
+                             "before the oldest is waited for, each on 1 / frames_in_flight of the CUs; the time includes filling and draining the pipeline")
     extras = {}
     if world > 1 and not args.no_extras:
         if args.scaling != "weak":
@@ -518,6 +550,8 @@ def main():
         out["extras"] = extras
     if per_frame is not None:
         out["frame_by_frame"] = per_frame
+    if pipelined is not None:
+        out["pipelined"] = pipelined
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -17,7 +17,8 @@
  * the device-buffer entry points keep a context's launches in order: a launch on a different
  * stream than the previous one is queued behind it (hipStreamWaitEvent), it does not overlap it.
  * To overlap renders on one GPU use two contexts; to use several GPUs use one context per GPU
- * (rt_render_multi below, or one process per GPU).
+ * (rt_render_multi below, or one process per GPU).  The exception is rt_frame_submit / rt_frame_collect:
+ * up to RT_PIPELINE_DEPTH progressive frames of one context in flight, each with scratch of its own.
  */
 #ifndef RT_AMD_H
 #define RT_AMD_H
@@ -37,7 +38,8 @@ enum {
     RT_ERR_UNSUPPORTED = 3,  /* e.g. "Only triangle or quad meshes are supported." (src/main.cu:141) */
     RT_ERR_HIP = 4,          /* "Error from HIP (<what>): <hipGetErrorString>"  (src/utils.cu:5-10) */
     RT_ERR_NOMEM = 5,
-    RT_ERR_NO_DEVICE = 6     /* the HIP runtime reports no usable GPU: there is NO CPU fallback */
+    RT_ERR_NO_DEVICE = 6,    /* the HIP runtime reports no usable GPU: there is NO CPU fallback */
+    RT_ERR_BUSY = 7          /* rt_frame_submit: RT_PIPELINE_DEPTH frames are in flight */
 };
 
 typedef struct rt_ctx rt_ctx;
@@ -221,6 +223,43 @@ rt_status rt_render_device(rt_ctx *ctx, const rt_scene *scene, const rt_camera *
 rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
                                  const int32_t *times_ms, int32_t n_frames, int32_t frame_num, const rt_tile_spec *tiles,
                                  float *d_frame, void *hip_stream);
+/* Pipelined frames: the reference's main loop (src/main.cu:415-431: seed from the wall clock, render(), draw, poll) with the next
+ * frame's launch issued BEFORE the previous frame is waited for.  A 1920x1080x1024-spp frame is as long as its most expensive
+ * pixel - half of it runs on a nearly empty GPU - and rt_render_device_batch only fills that time when the
+ * seeds of the coming frames are known in advance, which a loop that draws each seed at call time cannot offer.  Here it can:
+ *   rt_frame_submit   queues ONE frame seeded with time_ms on a stream of the context's own (up to rt_frame_depth submitted
+ *                     and not yet collected; RT_ERR_BUSY beyond).  The frame's per-pixel means go to a plane the context keeps;
+ *                     nothing the caller owns is touched.  Frames in flight run side by side on the GPU.
+ *   rt_frame_collect  takes the OLDEST submitted frame: on `hip_stream`, behind that frame's render kernel, folds it into d_frame
+ *                     as progressive frame `frame_num` ((c + prev * frame_num) / (frame_num + 1), src/raytracer.cu:109-112; d_frame
+ *                     has the layout of rt_render_device's d_out for the tile spec the frame was submitted with, and is ignored
+ *                     as input when frame_num == 0).  Asynchronous like rt_render_device.  d_frame == NULL discards the frame
+ *                     (the camera moved: the reference restarts at frame 0, src/main.cu:392-407).
+ * Frames are collected in submission order, and the image after collecting frames 0..k is bit-identical to k + 1 calls of
+ * rt_render_device with the same seeds (tests/test_gpu_pipeline.py).  The loop becomes
+ *     submit(t0); for (;;) { submit(now()); collect(n++, d_frame, s); draw(d_frame); }
+ * i.e. the picture on screen lags the newest seed by the frames in flight.  Measured (monkey, 1920x1080x1024 spp, bench.py
+ * "pipelined"): 4 in flight 8,200 Msamples/s against 4,550 one launch at a time and 10,270 for rt_render_device_batch.
+ * A view's first frame or two (new scene / camera / size / tile spec) run alone: they measure the tiles and sort the schedule,
+ * and the host waits for the frames in flight before it rewrites either.  rt_last_kernel_ms does not see pipelined frames;
+ * rt_ctx_synchronize waits for them; launches of the other entry points are queued behind them. */
+#define RT_PIPELINE_DEPTH 8            /* at most */
+#define RT_PIPELINE_DEFAULT_DEPTH 4
+/* How many frames the caller is going to keep in flight (1..RT_PIPELINE_DEPTH; a context starts with RT_PIPELINE_DEFAULT_DEPTH):
+ * rt_frame_submit refuses more, and every frame is launched on 1 / depth of the GPU's CUs - `depth` frames side by side, each
+ * bound by its work instead of by its longest pixel (alone on the GPU a frame leaves most CUs idle for half its duration).
+ * Throughput grows with the depth, and so does a frame's latency (depth x the time per frame).  depth 1 is rt_render_device
+ * with a plane in between.  Only while no frame is in flight (RT_ERR_BUSY otherwise). */
+rt_status rt_frame_depth(rt_ctx *ctx, int32_t depth);
+rt_status rt_frame_submit(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
+                          int32_t time_ms, const rt_tile_spec *tiles);
+rt_status rt_frame_collect(rt_ctx *ctx, int32_t frame_num, float *d_frame, void *hip_stream);
+/* frames submitted and not collected */
+int32_t rt_frames_pending(const rt_ctx *ctx);
+/* blocks until the frame collected last has been folded into its d_frame (what a host that draws the frame itself waits for:
+ * the cudaDeviceSynchronize of src/dispatch.cu:141 for this loop) - the younger frames keep running */
+rt_status rt_frame_wait(rt_ctx *ctx);
+
 /* number of rows a rank owns under a band tile spec (host helper for sizing compact buffers) */
 int32_t rt_tile_owned_rows(const rt_tile_spec *tiles, int32_t height);
 

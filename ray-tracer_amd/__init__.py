@@ -21,7 +21,7 @@ from . import scenes  # noqa: F401  (re-exported)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-RT_OK, RT_ERR_INVALID, RT_ERR_IO, RT_ERR_UNSUPPORTED, RT_ERR_HIP, RT_ERR_NOMEM, RT_ERR_NO_DEVICE = range(7)
+RT_OK, RT_ERR_INVALID, RT_ERR_IO, RT_ERR_UNSUPPORTED, RT_ERR_HIP, RT_ERR_NOMEM, RT_ERR_NO_DEVICE, RT_ERR_BUSY = range(8)
 TEX_COLOUR, TEX_GRADIENT, TEX_CHECKERBOARD, TEX_IMAGE = 0, 1, 2, 3
 MAT_STANDARD, MAT_EMISSIVE, MAT_REFRACTIVE = 0, 1, 2
 
@@ -80,6 +80,7 @@ ABI_SYMBOLS = [
     "rt_scene_get_info", "rt_render", "rt_render_frames", "rt_render_device", "rt_render_device_batch", "rt_tile_owned_rows", "rt_last_kernel_ms",
     "rt_tile_costs", "rt_partition_tiles", "rt_tiles_copy_device", "rt_max_batch_frames", "rt_peer_access",
     "rt_ctx_synchronize", "rt_render_multi", "rt_render_multi_device", "rt_gather",
+    "rt_frame_submit", "rt_frame_collect", "rt_frames_pending", "rt_frame_wait", "rt_frame_depth",
     "rt_to_rgba8_device", "rt_debug_flatten", "rt_debug_read_stats", "rt_debug_eval", "rt_debug_exhaustive", "rt_version",
 ]
 
@@ -169,6 +170,12 @@ def lib():
     L.rt_render_device_batch.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
                                          C.POINTER(rt_tile_spec), vp, vp]
     L.rt_tile_owned_rows.argtypes = [C.POINTER(rt_tile_spec), C.c_int32]
+    if hasattr(L, "rt_frame_submit"):            # (absent from development builds of older revisions)
+        L.rt_frame_submit.argtypes = [vp, vp, C.POINTER(rt_camera), C.POINTER(rt_render_settings), C.c_int32, C.POINTER(rt_tile_spec)]
+        L.rt_frame_collect.argtypes = [vp, C.c_int32, vp, vp]
+        L.rt_frames_pending.argtypes = [vp]
+        L.rt_frame_wait.argtypes = [vp]
+        L.rt_frame_depth.argtypes = [vp, C.c_int32]
     u32p = C.POINTER(C.c_uint32)
     L.rt_tile_costs.argtypes = [vp, u32p, u32p, u32p, C.c_int32, C.POINTER(C.c_int32)]
     L.rt_partition_tiles.argtypes = [u32p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
@@ -195,6 +202,10 @@ def lib():
 
 class RayTracerError(RuntimeError):
     """std::runtime_error of the reference (check_cuda_error src/utils.cu:5-10, read_file src/obj_read.cu:10)."""
+
+
+class PipelineFullError(RayTracerError):
+    """rt_frame_submit: RT_PIPELINE_DEPTH frames are in flight (RT_ERR_BUSY)"""
 
 
 class UnsupportedMeshError(ValueError):
@@ -536,6 +547,8 @@ class Context:
                 raise NotImplementedError(msg)
             if st == RT_ERR_INVALID:
                 raise ValueError(msg)
+            if st == RT_ERR_BUSY:
+                raise PipelineFullError(msg)
             raise RayTracerError(msg)
 
     def last_error(self):
@@ -677,6 +690,40 @@ def render_device_batch(ctx, scene, camera, render_data, times_ms, frame_num, d_
     ctx._check(lib().rt_render_device_batch(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), t, len(times_ms), int(frame_num),
                                             C.byref(ts), C.c_void_p(d_frame), C.c_void_p(stream or 0)))
     del keep
+
+
+PIPELINE_DEPTH = 8          # RT_PIPELINE_DEPTH (include/rt_amd.h): at most
+PIPELINE_DEFAULT_DEPTH = 4
+
+
+def frame_depth(ctx, depth):
+    """how many frames the caller keeps in flight: each is launched on 1 / depth of the CUs (rt_frame_depth)"""
+    ctx._check(lib().rt_frame_depth(ctx._h, int(depth)))
+
+
+
+def frame_submit(ctx, scene, camera, render_data, time_ms,
+                 band_rows=8, band_first=0, band_stride=1, compact=False, tile_list=None, tile_cost=None, tile_peak=None):
+    """Queue one frame seeded with time_ms on a stream of the context's own; up to PIPELINE_DEPTH may be submitted and not
+    collected (rt_frame_submit).  Frames in flight overlap on the GPU."""
+    ts, keep = _tile_spec(band_rows, band_first, band_stride, compact, tile_list, tile_cost, tile_peak)
+    ctx._check(lib().rt_frame_submit(ctx._h, scene._h, C.byref(camera.c), C.byref(render_data.c), int(time_ms), C.byref(ts)))
+    del keep
+
+
+def frame_collect(ctx, frame_num, d_frame, stream=None):
+    """Fold the oldest submitted frame into the device buffer d_frame as progressive frame frame_num, asynchronously on
+    `stream` (rt_frame_collect).  d_frame None: discard the frame."""
+    ctx._check(lib().rt_frame_collect(ctx._h, int(frame_num), C.c_void_p(d_frame or 0), C.c_void_p(stream or 0)))
+
+
+def frame_wait(ctx):
+    """block until the frame collected last is in its d_frame (rt_frame_wait)"""
+    ctx._check(lib().rt_frame_wait(ctx._h))
+
+
+def frames_pending(ctx):
+    return int(lib().rt_frames_pending(ctx._h))
 
 
 def partition_tiles(width, height, n_ranks, cost=None):

@@ -71,6 +71,33 @@ struct MultiState {
 
 }  // namespace
 
+/* One frame in flight of the pipelined per-frame entry points (rt_frame_submit / rt_frame_collect): everything a launch
+ * writes that the context otherwise holds once - its stream, its ticket counter, the plane its pixels' means go to. */
+struct FrameSlot {
+    hipStream_t stream = nullptr;
+    uint32_t *counter = nullptr;        /* 1 KB like rt_ctx::tile_counter */
+    float *plane = nullptr;
+    size_t plane_cap = 0;               /* floats */
+    hipEvent_t ev_done = nullptr;       /* the frame's render kernel has finished (recorded on `stream`) */
+    hipEvent_t ev_free = nullptr;       /* the blend that read the plane has finished (recorded on `stream` too: the blend runs there) */
+    hipEvent_t ev_call = nullptr;       /* where the collector's stream stood when it asked for the frame */
+    bool used = false, folded = false;  /* ev_done / ev_free have been recorded at least once */
+    /* what rt_frame_collect needs to fold the plane into the caller's frame (the launch's output layout) */
+    size_t plane_floats = 0;
+    int compact = 0, listed = 0, band_rows = 8, band_first = 0, band_stride = 1, width = 0, height = 0, tiles_x = 0, n_tiles = 0;
+};
+
+struct Pipeline {
+    FrameSlot slots[RT_PIPELINE_DEPTH];
+    int order[RT_PIPELINE_DEPTH];       /* submitted and not collected, oldest first */
+    int pending = 0;
+    int depth = RT_PIPELINE_DEFAULT_DEPTH;   /* rt_frame_depth: how many frames the caller keeps in flight */
+    int last_fold = -1;                 /* the slot whose frame was folded last (folds into one frame happen in collection order) */
+    uint32_t *d_list = nullptr;         /* the view's tile list (listed tile specs), shared by the frames in flight */
+    size_t list_cap = 0;
+    std::vector<uint32_t> list_host;
+};
+
 struct rt_ctx {
     int device = 0;
     int num_cus = 0;
@@ -137,6 +164,7 @@ struct rt_ctx {
     int hit_break = RT_DEF_HIT_BREAK;          /* lanes; RT_AMD_HIT_BREAK */
     int hit_low = RT_DEF_HIT_LOW, mix_break = RT_DEF_MIX_BREAK;   /* RT_AMD_HIT_LOW, RT_AMD_MIX_BREAK (0 = that rule off) */
     int shade_batch = RT_DEF_SHADE_BATCH;        /* lanes; RT_AMD_SHADE_BATCH (1..64) */
+    Pipeline pipe;
     int multi_careful = 0;                       /* RT_AMD_MULTI_CAREFUL=1: rt_render_multi_device waits on the host after every phase (diagnosis) */
 };
 
@@ -365,6 +393,15 @@ extern "C" void rt_ctx_destroy(rt_ctx *ctx)
     if (ctx->d_job_order) (void)hipFree(ctx->d_job_order);
     if (ctx->d_partial) (void)hipFree(ctx->d_partial);
     if (ctx->d_bands) (void)hipFree(ctx->d_bands);
+    for (FrameSlot &fs : ctx->pipe.slots) {
+        if (fs.stream) { (void)hipStreamSynchronize(fs.stream); (void)hipStreamDestroy(fs.stream); }
+        if (fs.counter) (void)hipFree(fs.counter);
+        if (fs.plane) (void)hipFree(fs.plane);
+        if (fs.ev_done) (void)hipEventDestroy(fs.ev_done);
+        if (fs.ev_free) (void)hipEventDestroy(fs.ev_free);
+        if (fs.ev_call) (void)hipEventDestroy(fs.ev_call);
+    }
+    if (ctx->pipe.d_list) (void)hipFree(ctx->pipe.d_list);
     for (DevList &dl : ctx->dev_lists) free_dev_list(dl);
     for (auto &kv : ctx->stages) {
         if (kv.second.d) (void)hipFree(kv.second.d);
@@ -607,6 +644,17 @@ uint32_t coprime_stride(uint32_t n)
 
 /* The view's measured costs are on the device (cost_state 1): bring them to the host on `stream` (one
  * synchronisation), and, when the view uses a tile order, move the `heavy_top` most expensive tiles to its front. */
+/* the render kernels of every pipelined frame have finished (host wait); with_folds: so have the blends that read their planes
+ * and the view's tile list */
+rt_status drain_pipeline(rt_ctx *ctx, bool with_folds)
+{
+    for (FrameSlot &fs : ctx->pipe.slots) {
+        if (fs.used) RT_HIP(ctx, hipEventSynchronize(fs.ev_done), "waiting for the frames in flight");
+        if (with_folds && fs.folded) RT_HIP(ctx, hipEventSynchronize(fs.ev_free), "waiting for the frames in flight");
+    }
+    return RT_OK;
+}
+
 rt_status read_costs_and_refine(rt_ctx *ctx, hipStream_t stream)
 {
     const uint32_t n = (uint32_t)ctx->tiles_host.size();
@@ -650,11 +698,36 @@ rt_status read_costs_and_refine(rt_ctx *ctx, hipStream_t stream)
 
 /* one launch rendering n_frames consecutive progressive frames (n_frames == 1: a plain frame with an
  * optional separate previous frame; > 1: d_out is updated in place) */
+/* (c + prev * n) / (n + 1) over the pixels a launch owns, frame by frame (src/raytracer.cu:109-112): `planes` holds n_frames planes of
+ * per-pixel means in the launch's output layout.  Compact layouts, and a full frame rendered whole: one pass over the buffer; a
+ * full-layout frame of which the launch owns some bands / tiles: only those are folded */
+static rt_status fold_planes(rt_ctx *ctx, const float *planes, size_t plane_floats, int n_frames, int frame_num, float *d_out, int compact, bool listed,
+                             const uint32_t *d_tile_list, int n_tiles, int tiles_x, int band_rows, int band_first, int band_stride, int width, int height,
+                             hipStream_t stream)
+{
+    if (compact || (!listed && band_stride == 1)) {
+        RT_HIP(ctx, rt_launch_blend(planes, (long long)plane_floats, n_frames, frame_num, d_out, (long long)plane_floats, stream), "launching blend kernel");
+    } else if (listed) {
+        RT_HIP(ctx, rt_launch_blend_tiles(planes, (long long)plane_floats, n_frames, frame_num, d_out, d_tile_list, n_tiles, tiles_x, width, height, stream),
+               "launching blend kernel");
+    } else {
+        const int bands_total = (height + band_rows - 1) / band_rows;
+        for (int b = band_first; b < bands_total; b += band_stride) {
+            const int row0 = b * band_rows, row1 = row0 + band_rows < height ? row0 + band_rows : height;
+            const long long off = (long long)row0 * width * 3, cnt = (long long)(row1 - row0) * width * 3;
+            RT_HIP(ctx, rt_launch_blend(planes + off, (long long)plane_floats, n_frames, frame_num, d_out + off, cnt, stream), "launching blend kernel");
+        }
+    }
+    return RT_OK;
+}
+
+/* slot != NULL: a pipelined frame (rt_frame_submit) - the launch runs on the slot's stream with the slot's ticket counter, its
+ * pixels' means go to the slot's plane and nothing is folded here; d_prev, d_out and hip_stream are not used. */
 static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
                                const int32_t *times_ms, int32_t n_frames, int32_t frame_num, const rt_tile_spec *tiles,
-                               const float *d_prev, float *d_out, void *hip_stream, bool in_place)
+                               const float *d_prev, float *d_out, void *hip_stream, bool in_place, FrameSlot *slot = nullptr)
 {
-    if (!ctx || !scene || !cam || !rs || !d_out) return set_err(ctx, RT_ERR_INVALID, "null argument");
+    if (!ctx || !scene || !cam || !rs || (!d_out && !slot)) return set_err(ctx, RT_ERR_INVALID, "null argument");
     if (scene->ctx != ctx) return set_err(ctx, RT_ERR_INVALID, "scene belongs to another context");
     if (cam->width <= 0 || cam->height <= 0 || cam->width > 32768 || cam->height > 32768 || (int64_t)cam->width * cam->height > (1 << 28))
         return set_err(ctx, RT_ERR_INVALID, "bad image size (at most 32768 pixels on a side and 2^28 in all)");
@@ -672,10 +745,15 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
         if (t->band_rows <= 0 || (t->band_rows & 7) || t->band_stride <= 0 || t->band_first < 0 || t->band_first >= t->band_stride)
             return set_err(ctx, RT_ERR_INVALID, "bad tile spec (band_rows must be a positive multiple of 8, 0 <= band_first < band_stride)");
     }
-    hipStream_t stream = (hipStream_t)hip_stream;
+    hipStream_t stream = slot ? slot->stream : (hipStream_t)hip_stream;
     RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
-    /* one launch in flight per context: the scratch is shared (see rt_ctx) */
-    if (ctx->launched && ctx->last_stream != stream) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_stop, 0), "ordering the launch behind the previous one");
+    /* one launch in flight per context: the scratch is shared (see rt_ctx) ... */
+    if (ctx->launched && (slot || ctx->last_stream != stream)) RT_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_stop, 0), "ordering the launch behind the previous one");
+    /* ... except pipelined frames, which bring their own (FrameSlot) and only read the view's: they overlap each other, and an
+     * ordinary launch is queued behind all of them */
+    if (!slot)
+        for (FrameSlot &fs : ctx->pipe.slots)
+            if (fs.used) RT_HIP(ctx, hipStreamWaitEvent(stream, fs.ev_done, 0), "ordering the launch behind the frames in flight");
 
     rt_kernel_args a;
     std::memset(&a, 0, sizeof a);
@@ -724,8 +802,8 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
     a.tex_data = scene->d_tex;
     a.prev = d_prev;
     a.out = d_out;
-    a.tile_counter = ctx->tile_counter;
-    a.stats = (unsigned long long *)(ctx->tile_counter + 16);   /* 48 x u64 after the counter; used by -DRT_STATS builds only */
+    a.tile_counter = slot ? slot->counter : ctx->tile_counter;
+    a.stats = (unsigned long long *)(a.tile_counter + 16);   /* 48 x u64 after the counter; used by -DRT_STATS builds only */
 
 
     /* one plane of the launch's output layout (floats) */
@@ -748,7 +826,37 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
         } else {
             key.push_back((uint32_t)a.band_rows); key.push_back((uint32_t)a.band_first); key.push_back((uint32_t)a.band_stride);
         }
-        if (key != ctx->order_key) {
+        /* a pixel's cost counter is 26 bits wide (rt_device_scene.h RT_COST_*): launches that could overflow it (65,536 or
+         * more bounces per pixel) do not collect costs and run on the schedule the view already has */
+        const bool cost_fits = (long long)rs->rays_per_pixel * (long long)(rs->reflection_limit > 0 ? rs->reflection_limit : 1) < 65536ll;
+        /* figures from a launch with far fewer samples (a 1-spp preview, a profiler's warm-up launch) are provisional
+         * like a pilot's: this launch runs on them and measures again */
+        const bool new_view = key != ctx->order_key;
+        const bool provisional = !new_view && ctx->cost_state == 2 && ctx->cost_spp > 0 && (long long)ctx->cost_spp * 8 <= (long long)rs->rays_per_pixel &&
+                                 !(listed && t->tile_cost) && cost_fits;
+        if (slot) {
+            /* Pipelined frames overlap as long as they only READ the view (tile order, tile list).  A launch that writes it - a
+             * new view, a pilot, a launch that measures tile costs, the one that sorts by them - first waits (on the host)
+             * for the frames in flight: once or twice per view. */
+            const bool will_pilot = ctx->pilot && ctx->use_order && rs->rays_per_pixel >= ctx->pilot_min_spp && rs->reflection_limit > 0;
+            const bool list_changed = listed && (ctx->pipe.list_host.size() != (size_t)n || std::memcmp(ctx->pipe.list_host.data(), t->tile_list, (size_t)n * 4) != 0);
+            if (list_changed)
+                for (int j = 0; j < ctx->pipe.pending; j++)
+                    if (ctx->pipe.slots[ctx->pipe.order[j]].listed)
+                        return set_err(ctx, RT_ERR_BUSY, "frames of another tile list are waiting to be collected (rt_frame_collect; d_frame == NULL discards one)");
+            if (new_view || list_changed || (ctx->cost_state == 0 && (cost_fits || will_pilot)) || (ctx->cost_state == 1 && ctx->use_order) || provisional) {
+                rt_status st = drain_pipeline(ctx, new_view || list_changed);
+                if (st != RT_OK) return st;
+            }
+            if (listed && (list_changed || !ctx->pipe.d_list)) {
+                rt_status st = grow_u32(ctx, &ctx->pipe.d_list, &ctx->pipe.list_cap, n, "allocating the pipeline's tile list");
+                if (st != RT_OK) return st;
+                ctx->pipe.list_host.clear();
+                RT_HIP(ctx, hipMemcpy(ctx->pipe.d_list, t->tile_list, (size_t)n * 4, hipMemcpyHostToDevice), "uploading the pipeline's tile list");
+                ctx->pipe.list_host.assign(t->tile_list, t->tile_list + n);
+            }
+        }
+        if (new_view) {
             /* a new view.  local tile -> tile of the image */
             std::vector<uint32_t> th(n);
             if (listed) {
@@ -826,7 +934,9 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
             }
             ctx->order_key = key;
         }
-        if (listed) {
+        if (listed && slot) {
+            a.tile_list = ctx->pipe.d_list;
+        } else if (listed) {
             rt_status st = device_tile_list(ctx, t->tile_list, (int)n, stream, &a.tile_list);
             if (st != RT_OK) return st;
         }
@@ -834,9 +944,6 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
          * synchronisation) and moves the `heavy_top` most expensive tiles to the front of the order, most expensive
          * first within rounds of one ticket per wave.  In a multi-frame launch those tiles go first for ALL frames
          * (see px_fetch): with the true costs that is worth 10 % at three frames per launch (with the guess, nothing). */
-        /* a pixel's cost counter is 26 bits wide (rt_device_scene.h RT_COST_*): launches that could overflow it (65,536 or
-         * more bounces per pixel) do not collect costs and run on the schedule the view already has */
-        const bool cost_fits = (long long)rs->rays_per_pixel * (long long)(rs->reflection_limit > 0 ? rs->reflection_limit : 1) < 65536ll;
         if (ctx->cost_state == 0) {
             /* Pilot: a view's first launch would run on the guessed order (measured: 315 instead of 228 ms per frame for
              * the monkey's first five frames).  One sample per pixel of the launch's first frame, rendered into a scratch
@@ -856,7 +963,7 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
                 ap.tile_peak = ctx->d_tile_peak;
                 RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)n * 4, stream), "clearing tile costs");
                 RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_peak, 0, (size_t)n * 4, stream), "clearing tile costs");
-                RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 512, stream), "clearing tile counter");
+                RT_HIP(ctx, hipMemsetAsync(ap.tile_counter, 0, 512, stream), "clearing tile counter");
                 RT_HIP(ctx, rt_launch_render(&ap, scene->flat.has_mesh ? 1 : 0, scene->scene_in_lds, scene->threads, launch_blocks(ctx, scene, (int)n), scene->lds_bytes, stream),
                        "launching the pilot");
                 ctx->cost_state = 1; ctx->cost_spp = 1;
@@ -874,9 +981,7 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
                 rt_status st = read_costs_and_refine(ctx, stream);
                 if (st != RT_OK) return st;
             }
-            /* figures from a launch with far fewer samples (a 1-spp preview, a profiler's warm-up launch) are provisional
-             * like a pilot's: this launch runs on them and measures again */
-            if (ctx->cost_state == 2 && ctx->cost_spp > 0 && (long long)ctx->cost_spp * 8 <= (long long)rs->rays_per_pixel && !(listed && t->tile_cost) && cost_fits) {
+            if (provisional && ctx->cost_state == 2) {
                 RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_cost, 0, (size_t)n * 4, stream), "clearing tile costs");
                 RT_HIP(ctx, hipMemsetAsync(ctx->d_tile_peak, 0, (size_t)n * 4, stream), "clearing tile costs");
                 a.tile_cost = ctx->d_tile_cost;
@@ -911,37 +1016,49 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
             }
         }
     }
-    if (in_place) {
+    if (slot) {
+        if (slot->plane_cap < plane_floats && slot->folded) RT_HIP(ctx, hipEventSynchronize(slot->ev_free), "waiting for a frame's blend");   /* (the plane is about to be replaced) */
+        rt_status st = grow(ctx, &slot->plane, &slot->plane_cap, plane_floats, "allocating a pipelined frame's plane");
+        if (st != RT_OK) return st;
+        a.partial = slot->plane;
+        a.partial_plane = (int64_t)(plane_floats / 3);
+        slot->plane_floats = plane_floats; slot->compact = a.compact; slot->listed = listed ? 1 : 0;
+        slot->band_rows = a.band_rows; slot->band_first = a.band_first; slot->band_stride = a.band_stride;
+        slot->width = cam->width; slot->height = cam->height; slot->tiles_x = tiles_x; slot->n_tiles = a.num_tiles;
+    } else if (in_place) {
         const size_t need = plane_floats * (size_t)n_frames;
         rt_status st = grow(ctx, &ctx->d_partial, &ctx->partial_cap, need, "allocating the per-frame planes of a multi-frame launch");
         if (st != RT_OK) return st;
         a.partial = ctx->d_partial;
         a.partial_plane = (int64_t)(plane_floats / 3);
     }
-    RT_HIP(ctx, hipEventRecord(ctx->ev_start, stream), "recording start event");
-    ctx->have_timing = false;
+    if (!slot) {
+        RT_HIP(ctx, hipEventRecord(ctx->ev_start, stream), "recording start event");
+        ctx->have_timing = false;
+    }
     if (a.num_tiles > 0) {
-        const int blocks = launch_blocks(ctx, scene, a.num_tiles);
-        RT_HIP(ctx, hipMemsetAsync(ctx->tile_counter, 0, 512, stream), "clearing tile counter");
+        int blocks = launch_blocks(ctx, scene, a.num_tiles);
+        if (slot) {
+            /* A pipelined frame gets its share of the CUs, not all of them: a frame alone on the GPU is as long as its longest
+             * pixel and leaves most CUs idle (or held by a workgroup with one busy wave) for half of that time; on 1 / depth of
+             * the CUs the same frame is bound by its work instead, and `depth` of them fill the GPU (measured, monkey 1080p
+             * 1024 spp, 4 in flight: 286 ms per frame with full-size launches, 242 with quarter-size ones). */
+            const int d = ctx->pipe.depth;
+            blocks = (blocks + d - 1) / d;
+        }
+        RT_HIP(ctx, hipMemsetAsync(a.tile_counter, 0, 512, stream), "clearing tile counter");
         RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
         if (collecting) { ctx->cost_state = 1; ctx->cost_spp = rs->rays_per_pixel; }   /* only now: a failed launch leaves no costs to sort on */
     }
+    if (slot) {
+        RT_HIP(ctx, hipEventRecord(slot->ev_done, stream), "recording a pipelined frame's end");
+        slot->used = true;
+        return RT_OK;
+    }
     if (in_place && a.num_tiles > 0) {
-        /* the pixels this launch owns.  Compact layouts, and a full frame rendered whole: one pass over the buffer;
-         * a full-layout frame of which the launch owns some bands / tiles: only those are folded */
-        if (a.compact || (!listed && a.band_stride == 1)) {
-            RT_HIP(ctx, rt_launch_blend(ctx->d_partial, (long long)plane_floats, n_frames, frame_num, d_out, (long long)plane_floats, stream), "launching blend kernel");
-        } else if (listed) {
-            RT_HIP(ctx, rt_launch_blend_tiles(ctx->d_partial, (long long)plane_floats, n_frames, frame_num, d_out, a.tile_list, (int)n, tiles_x, cam->width, cam->height, stream),
-                   "launching blend kernel");
-        } else {
-            const int bands_total = (cam->height + a.band_rows - 1) / a.band_rows;
-            for (int b = a.band_first; b < bands_total; b += a.band_stride) {
-                const int row0 = b * a.band_rows, row1 = row0 + a.band_rows < cam->height ? row0 + a.band_rows : cam->height;
-                const long long off = (long long)row0 * cam->width * 3, cnt = (long long)(row1 - row0) * cam->width * 3;
-                RT_HIP(ctx, rt_launch_blend(ctx->d_partial + off, (long long)plane_floats, n_frames, frame_num, d_out + off, cnt, stream), "launching blend kernel");
-            }
-        }
+        rt_status st = fold_planes(ctx, ctx->d_partial, plane_floats, n_frames, frame_num, d_out, a.compact, listed, a.tile_list, (int)n, tiles_x,
+                                   a.band_rows, a.band_first, a.band_stride, cam->width, cam->height, stream);
+        if (st != RT_OK) return st;
     }
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream), "recording stop event");
     ctx->have_timing = true;
@@ -971,6 +1088,106 @@ extern "C" rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, 
     return render_frames(ctx, scene, cam, rs, times_ms, n_frames, frame_num, tiles, nullptr, d_frame, hip_stream, true);
 }
 
+/* ---- pipelined frames --------------------------------------------------------------------------------------------------- */
+static rt_status init_slot(rt_ctx *ctx, FrameSlot &fs)
+{
+    if (fs.stream) return RT_OK;
+    {
+        /* Frames only overlap if their streams sit on different hardware queues.  The runtime keeps a pool of them per stream
+         * priority (four each by default, GPU_MAX_HW_QUEUES) and the caller's own streams - the null stream, PyTorch's - already
+         * live in the normal-priority pool: a fourth frame's stream would share a queue there and run behind its neighbour
+         * (measured: 4 in flight 333 ms per frame, worse than 3; with streams of the high-priority pool 286-290).  Slots 0-3 take
+         * the high-priority pool, 4-7 the low-priority one; the priority itself is immaterial (the frames are each other's only
+         * competitors: alternating the pools over the slots measures the same at every depth). */
+        int lo = 0, hi = 0;
+        const int k = (int)(&fs - ctx->pipe.slots);
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+            RT_HIP(ctx, hipStreamCreateWithPriority(&fs.stream, hipStreamNonBlocking, k < 4 ? hi : lo), "creating a pipelined frame's stream");
+        else
+            RT_HIP(ctx, hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking), "creating a pipelined frame's stream");
+    }
+    RT_HIP(ctx, hipMalloc((void **)&fs.counter, 1024), "allocating a pipelined frame's ticket counter");
+    RT_HIP(ctx, hipEventCreateWithFlags(&fs.ev_done, hipEventDisableTiming), "creating a pipelined frame's event");
+    RT_HIP(ctx, hipEventCreateWithFlags(&fs.ev_free, hipEventDisableTiming), "creating a pipelined frame's event");
+    RT_HIP(ctx, hipEventCreateWithFlags(&fs.ev_call, hipEventDisableTiming), "creating a pipelined frame's event");
+    return RT_OK;
+}
+
+extern "C" rt_status rt_frame_submit(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
+                                     int32_t time_ms, const rt_tile_spec *tiles)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    Pipeline &pl = ctx->pipe;
+    if (pl.pending >= pl.depth) return set_err(ctx, RT_ERR_BUSY, "as many frames as rt_frame_depth allows are in flight: collect one first");
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    /* a free slot: one that is not waiting to be collected */
+    int k = -1;
+    for (int i = 0; i < RT_PIPELINE_DEPTH && k < 0; i++) {
+        bool busy = false;
+        for (int j = 0; j < pl.pending; j++) busy = busy || pl.order[j] == i;
+        if (!busy) k = i;
+    }
+    FrameSlot &fs = pl.slots[k];
+    rt_status st = init_slot(ctx, fs);
+    if (st != RT_OK) return st;
+    /* (the slot's plane is rewritten behind the blend that read it last: that ran on the slot's stream) */
+    st = render_frames(ctx, scene, cam, rs, &time_ms, 1, 0, tiles, nullptr, nullptr, nullptr, true, &fs);
+    if (st != RT_OK) return st;
+    pl.order[pl.pending++] = k;
+    return RT_OK;
+}
+
+extern "C" rt_status rt_frame_collect(rt_ctx *ctx, int32_t frame_num, float *d_frame, void *hip_stream)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    Pipeline &pl = ctx->pipe;
+    if (pl.pending <= 0) return set_err(ctx, RT_ERR_INVALID, "no frame has been submitted");
+    if (frame_num < 0) return set_err(ctx, RT_ERR_INVALID, "bad frame number");
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    FrameSlot &fs = pl.slots[pl.order[0]];
+    if (d_frame && fs.n_tiles > 0) {
+        /* The blend runs on the frame's own stream, right behind its render kernel, and the caller's stream only waits for it
+         * (a kernel queued on the caller's stream may sit behind whatever shares that stream's hardware queue).  Ordered behind
+         * what the caller has queued so far (it may still be reading d_frame) and behind the previous frame's blend. */
+        hipStream_t stream = (hipStream_t)hip_stream;
+        RT_HIP(ctx, hipEventRecord(fs.ev_call, stream), "recording the collector's position");
+        RT_HIP(ctx, hipStreamWaitEvent(fs.stream, fs.ev_call, 0), "ordering the blend behind the collector's stream");
+        if (pl.last_fold >= 0 && pl.last_fold != pl.order[0])
+            RT_HIP(ctx, hipStreamWaitEvent(fs.stream, pl.slots[pl.last_fold].ev_free, 0), "ordering the blend behind the previous frame's");
+        rt_status st = fold_planes(ctx, fs.plane, fs.plane_floats, 1, frame_num, d_frame, fs.compact, fs.listed != 0, pl.d_list, fs.n_tiles, fs.tiles_x,
+                                   fs.band_rows, fs.band_first, fs.band_stride, fs.width, fs.height, fs.stream);
+        if (st != RT_OK) return st;
+        RT_HIP(ctx, hipEventRecord(fs.ev_free, fs.stream), "recording a pipelined frame's blend");
+        fs.folded = true;
+        pl.last_fold = pl.order[0];
+        RT_HIP(ctx, hipStreamWaitEvent(stream, fs.ev_free, 0), "ordering the collector's stream behind the blend");
+    }
+    for (int j = 1; j < pl.pending; j++) pl.order[j - 1] = pl.order[j];
+    pl.pending--;
+    return RT_OK;
+}
+
+extern "C" int32_t rt_frames_pending(const rt_ctx *ctx) { return ctx ? ctx->pipe.pending : 0; }
+
+extern "C" rt_status rt_frame_depth(rt_ctx *ctx, int32_t depth)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    if (depth < 1 || depth > RT_PIPELINE_DEPTH) return set_err(ctx, RT_ERR_INVALID, "the depth of the frame pipeline is 1..RT_PIPELINE_DEPTH");
+    if (ctx->pipe.pending > 0) return set_err(ctx, RT_ERR_BUSY, "frames are in flight: collect them before changing the depth");
+    ctx->pipe.depth = depth;
+    return RT_OK;
+}
+
+extern "C" rt_status rt_frame_wait(rt_ctx *ctx)
+{
+    if (!ctx) return RT_ERR_INVALID;
+    const Pipeline &pl = ctx->pipe;
+    if (pl.last_fold < 0) return RT_OK;
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    RT_HIP(ctx, hipEventSynchronize(pl.slots[pl.last_fold].ev_free), "waiting for the collected frame");
+    return RT_OK;
+}
+
 extern "C" rt_status rt_tile_costs(rt_ctx *ctx, uint32_t *tile_ids, uint32_t *costs, uint32_t *peaks, int32_t capacity, int32_t *count)
 {
     if (!ctx || !count || capacity < 0 || (capacity > 0 && (!tile_ids || !costs))) return set_err(ctx, RT_ERR_INVALID, "null argument");
@@ -978,7 +1195,9 @@ extern "C" rt_status rt_tile_costs(rt_ctx *ctx, uint32_t *tile_ids, uint32_t *co
     RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
     if (ctx->order_key.empty() || ctx->cost_state == 0) return set_err(ctx, RT_ERR_INVALID, "no launch of the current view has collected tile costs");
     if (ctx->cost_state == 1) {
-        rt_status st = read_costs_and_refine(ctx, ctx->last_stream);
+        rt_status st = drain_pipeline(ctx, false);       /* (a pipelined frame may be the launch that measures, or be reading the order) */
+        if (st != RT_OK) return st;
+        st = read_costs_and_refine(ctx, ctx->last_stream);
         if (st != RT_OK) return st;
     }
     const size_t n = ctx->tiles_host.size();
@@ -1127,6 +1346,10 @@ extern "C" rt_status rt_ctx_synchronize(rt_ctx *ctx)
 {
     if (!ctx) return RT_ERR_INVALID;
     RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    {
+        rt_status st = drain_pipeline(ctx, true);
+        if (st != RT_OK) return st;
+    }
     if (!ctx->launched) return RT_OK;
     RT_HIP(ctx, hipEventSynchronize(ctx->ev_stop), "waiting for render kernel");
     return RT_OK;

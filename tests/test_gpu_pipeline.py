@@ -1,0 +1,216 @@
+"""Pipelined frames (rt_frame_submit / rt_frame_collect): the reference's main loop (src/main.cu:415-431) with the next frame's
+launch issued before the previous frame is waited for.  Up to RT_PIPELINE_DEPTH frames of one context run side by side on the
+GPU; the image after collecting frames 0..k must be the image of k + 1 rt_render_device calls - and of the oracle's progressive
+loop - bit for bit, whatever the depth, the scene kind, the tile spec or what else the context is asked to do in between."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def eq(a, b):
+    return np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32), np.ascontiguousarray(b, np.float32).view(np.uint32))
+
+
+def frame_by_frame(rt, ctx, scene, cam, rd, times, W, H, st, **spec):
+    import torch
+    a = torch.zeros((H, W, 3), device="cuda:0"); b = torch.zeros_like(a)
+    for i, t in enumerate(times):
+        rt.render_device(ctx, scene, cam, rd, t, i, b.data_ptr(), d_prev=a.data_ptr() if i else None, stream=st, **spec)
+        a, b = b, a
+    return a.cpu().numpy()
+
+
+def pipelined(rt, ctx, scene, cam, rd, times, d_frame, st, depth, first_frame=0, **spec):
+    """the loop of include/rt_amd.h: keep `depth` frames in flight, collect the oldest"""
+    n = first_frame
+    rt.frame_depth(ctx, depth)
+    for t in times:
+        if rt.frames_pending(ctx) == depth:
+            rt.frame_collect(ctx, n, d_frame, stream=st); n += 1
+        rt.frame_submit(ctx, scene, cam, rd, t, **spec)
+    while rt.frames_pending(ctx):
+        rt.frame_collect(ctx, n, d_frame, stream=st); n += 1
+    return n
+
+
+@pytest.mark.parametrize("name,W,H,spp,limit,frames", [("monkey", 200, 120, 6, 8, 9), ("three_sphere", 160, 96, 4, 8, 7),
+                                                       ("reference_scene0", 125, 100, 3, 5, 6), ("cube", 96, 64, 40, 8, 10),   # (40 spp: with a pilot launch)
+                                                       ("reference_scene3", 96, 72, 3, 8, 5), ("reference_scene4", 120, 68, 2, 6, 6)])
+def test_pipelined_frames_equal_frame_by_frame(rt, orc, models_dir, name, W, H, spp, limit, frames):
+    import torch
+    ctx = rt.Context(0)
+    objs, sky = rt.scenes.CONFIG_SCENES[name]()
+    scene = ctx.commit(rt.SceneObjects(objs))
+    cam, rd = rt.Camera(W, H), rt.RenderData(spp, limit, True, sky)
+    times = [-77 + 1009 * i for i in range(frames)]
+    st = torch.cuda.current_stream().cuda_stream
+    want = frame_by_frame(rt, ctx, scene, cam, rd, times, W, H, st)
+    for depth in (1, 2, rt.PIPELINE_DEFAULT_DEPTH, rt.PIPELINE_DEPTH):
+        fr = torch.full((H, W, 3), 7.0, device="cuda:0")            # garbage: frame 0 ignores it
+        assert pipelined(rt, ctx, scene, cam, rd, times, fr.data_ptr(), st, depth) == frames
+        assert eq(fr.cpu().numpy(), want), depth
+    # a context that has never seen the view (its first frames measure the tiles and sort the schedule while others queue up)
+    ctx2 = rt.Context(0)
+    scene2 = ctx2.commit(rt.SceneObjects(objs))
+    fr = torch.empty((H, W, 3), device="cuda:0")
+    pipelined(rt, ctx2, scene2, cam, rd, times, fr.data_ptr(), st, rt.PIPELINE_DEPTH)
+    assert eq(fr.cpu().numpy(), want)
+    if frames <= 6:
+        o = orc.Scene(objs, orc.MATH_DET, models_dir)
+        prev = None
+        for i, t in enumerate(times):
+            prev = o.render(cam.floats(), W, H, spp, limit, sky, time_ms=t, frame_num=i, prev=prev)
+        assert eq(want, prev)
+
+
+def test_pipeline_limits_and_discard(rt):
+    import torch
+    ctx = rt.Context(0)
+    objs, sky = rt.scenes.monkey()
+    scene = ctx.commit(rt.SceneObjects(objs))
+    W, H = 96, 64
+    cam, rd = rt.Camera(W, H), rt.RenderData(4, 8, True, sky)
+    st = torch.cuda.current_stream().cuda_stream
+    fr = torch.zeros((H, W, 3), device="cuda:0")
+    with pytest.raises(ValueError, match="no frame has been submitted"):
+        rt.frame_collect(ctx, 0, fr.data_ptr(), stream=st)
+    for i in range(rt.PIPELINE_DEFAULT_DEPTH):
+        rt.frame_submit(ctx, scene, cam, rd, 100 + i)
+    assert rt.frames_pending(ctx) == rt.PIPELINE_DEFAULT_DEPTH == 4
+    with pytest.raises(rt.PipelineFullError):
+        rt.frame_submit(ctx, scene, cam, rd, 999)
+    assert rt.frames_pending(ctx) == 4                              # (the refused frame left nothing behind)
+    with pytest.raises(rt.PipelineFullError, match="in flight"):
+        rt.frame_depth(ctx, 2)                                      # not while frames are in flight
+    for bad in (0, rt.PIPELINE_DEPTH + 1):
+        with pytest.raises(ValueError):
+            rt.frame_depth(ctx, bad)
+    # the camera "moves": frames 100 and 101 are shown, 102 and 103 discarded, the new view starts at frame 0
+    rt.frame_collect(ctx, 0, fr.data_ptr(), stream=st)
+    rt.frame_collect(ctx, 1, fr.data_ptr(), stream=st)
+    rt.frame_collect(ctx, 0, None)
+    rt.frame_collect(ctx, 0, None)
+    assert rt.frames_pending(ctx) == 0
+    assert eq(fr.cpu().numpy(), frame_by_frame(rt, ctx, scene, cam, rd, [100, 101], W, H, st))
+    cam2 = rt.Camera(W, H, pos=(0.3, 0.2, -0.5))
+    for i in range(3):
+        rt.frame_submit(ctx, scene, cam2, rd, 500 + i)
+    for i in range(3):
+        rt.frame_collect(ctx, i, fr.data_ptr(), stream=st)
+    assert eq(fr.cpu().numpy(), frame_by_frame(rt, ctx, scene, cam2, rd, [500, 501, 502], W, H, st))
+    with pytest.raises(ValueError):
+        rt.frame_collect(ctx, -1, fr.data_ptr(), stream=st)
+
+
+def test_pipelined_frames_mixed_with_the_other_entry_points(rt):
+    """ordinary launches of the same context (which share the view's tile order and may rewrite it) queue behind the frames in
+    flight; rt_ctx_synchronize waits for them; rt_tile_costs reads what a pipelined frame measured"""
+    import torch
+    ctx = rt.Context(0)
+    objs, sky = rt.scenes.monkey()
+    scene = ctx.commit(rt.SceneObjects(objs))
+    W, H = 176, 104
+    cam, rd = rt.Camera(W, H), rt.RenderData(5, 8, True, sky)
+    st = torch.cuda.current_stream().cuda_stream
+    times = list(range(40, 52))
+    want = frame_by_frame(rt, ctx, scene, cam, rd, times, W, H, st)
+    ctx2 = rt.Context(0)
+    scene2 = ctx2.commit(rt.SceneObjects(objs))
+    fr = torch.zeros((H, W, 3), device="cuda:0")
+    other = torch.zeros((H, W, 3), device="cuda:0")
+    s2 = torch.cuda.Stream()
+    rt.frame_submit(ctx2, scene2, cam, rd, times[0])                  # the view's first frame: measures the tiles
+    ids, cost = ctx2.tile_costs()                                     # ... and this reads them (waits for the frame)
+    assert cost.size == ((W + 7) // 8) * ((H + 7) // 8) and int((cost >> 1).max()) > 0
+    n = 0
+    for i, t in enumerate(times[1:]):
+        if rt.frames_pending(ctx2) == 3:                              # (of the default 4)
+            rt.frame_collect(ctx2, n, fr.data_ptr(), stream=st); n += 1
+        rt.frame_submit(ctx2, scene2, cam, rd, t)
+        if i % 4 == 1:        # an ordinary launch of another view in between (rewrites the context's tile order), on a third stream
+            rt.render_device(ctx2, scene2, rt.Camera(W, H, pos=(0.1 * i, 0.0, 0.0)), rd, 7, 0, other.data_ptr(), stream=s2.cuda_stream)
+        if i % 4 == 3:
+            rt.render_device_batch(ctx2, scene2, cam, rd, [1, 2, 3], 0, other.data_ptr(), stream=s2.cuda_stream)
+    while rt.frames_pending(ctx2):
+        rt.frame_collect(ctx2, n, fr.data_ptr(), stream=st); n += 1
+    assert n == len(times)
+    ctx2.synchronize()
+    torch.cuda.synchronize()
+    assert eq(fr.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_pipelined_frames_on_tile_lists_and_bands(rt, compact):
+    """the tile specs a rank of N GPUs renders with: the frames fold into the layout rt_render_device writes"""
+    import torch
+    dm = importlib.import_module("ray-tracer_amd.distributed")
+    ctx = rt.Context(0)
+    objs, sky = rt.scenes.monkey()
+    scene = ctx.commit(rt.SceneObjects(objs))
+    W, H = 200, 117                                                   # ragged
+    cam, rd = rt.Camera(W, H), rt.RenderData(4, 8, True, sky)
+    st = torch.cuda.current_stream().cuda_stream
+    times = [9, 8, 7, 6, 5, 4]
+    full = frame_by_frame(rt, ctx, scene, cam, rd, times, W, H, st)
+    lists = dm.tile_lists(dm.initial_ownership(W, H, 3), 3)
+    for spec_of in (lambda r: dict(tile_list=lists[r], compact=compact), lambda r: dict(band_first=r, band_stride=3, band_rows=16, compact=compact)):
+        got = torch.zeros((H, W, 3), device="cuda:0")
+        for r in range(3):
+            spec = spec_of(r)
+            if compact and "tile_list" in spec:
+                buf = torch.zeros(len(lists[r]) * 192, device="cuda:0")
+            elif compact:
+                buf = torch.zeros((dm.max_owned_rows(H, 16, 3), W, 3), device="cuda:0")
+            else:
+                buf = got
+            pipelined(rt, ctx, scene, cam, rd, times, buf.data_ptr(), st, rt.PIPELINE_DEPTH, **spec)
+            if compact and "tile_list" in spec:
+                rt.tiles_copy_device(ctx, buf.data_ptr(), got.data_ptr(), W, H, lists[r], to_frame=True, stream=st)
+            elif compact:
+                rows = [y for b in dm.owned_bands(H, 16, r, 3) for y in range(b * 16, min(H, b * 16 + 16))]
+                got[rows] = buf[:len(rows)]
+        torch.cuda.synchronize()
+        assert eq(got.cpu().numpy(), full)
+
+
+def test_a_changed_tile_list_with_frames_waiting_is_refused(rt):
+    import torch
+    dm = importlib.import_module("ray-tracer_amd.distributed")
+    ctx = rt.Context(0)
+    objs, sky = rt.scenes.monkey()
+    scene = ctx.commit(rt.SceneObjects(objs))
+    W, H = 96, 64
+    cam, rd = rt.Camera(W, H), rt.RenderData(2, 4, True, sky)
+    lists = dm.tile_lists(dm.initial_ownership(W, H, 2), 2)
+    rt.frame_submit(ctx, scene, cam, rd, 1, tile_list=lists[0])
+    with pytest.raises(rt.PipelineFullError, match="another tile list"):
+        rt.frame_submit(ctx, scene, cam, rd, 2, tile_list=lists[1])
+    rt.frame_collect(ctx, 0, None)
+    rt.frame_submit(ctx, scene, cam, rd, 2, tile_list=lists[1])
+    fr = torch.zeros((H, W, 3), device="cuda:0")
+    rt.frame_collect(ctx, 0, fr.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    want = torch.zeros((H, W, 3), device="cuda:0")
+    rt.render_device(ctx, scene, cam, rd, 2, 0, want.data_ptr(), tile_list=lists[1], stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert eq(fr.cpu().numpy(), want.cpu().numpy())
+
+
+def test_full_size_pipeline_property(rt):
+    """BASELINE's image size: 6 frames of the monkey configuration at 1920 x 1080 (16 spp), four in flight, against one multi-frame launch"""
+    import torch
+    ctx = rt.Context(0)
+    objs, sky = rt.scenes.monkey()
+    scene = ctx.commit(rt.SceneObjects(objs))
+    W, H = 1920, 1080
+    cam, rd = rt.Camera(W, H), rt.RenderData(16, 8, True, sky)
+    st = torch.cuda.current_stream().cuda_stream
+    times = [31337 + i for i in range(6)]
+    want = torch.zeros((H, W, 3), device="cuda:0")
+    rt.render_device_batch(ctx, scene, cam, rd, times, 0, want.data_ptr(), stream=st)
+    fr = torch.zeros((H, W, 3), device="cuda:0")
+    pipelined(rt, ctx, scene, cam, rd, times, fr.data_ptr(), st, rt.PIPELINE_DEPTH)
+    torch.cuda.synchronize()
+    assert torch.equal(fr.view(torch.int32), want.view(torch.int32))
