@@ -239,7 +239,8 @@ rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, const rt_ca
  * rt_render_device with the same seeds (tests/test_gpu_pipeline.py).  The loop becomes
  *     submit(t0); for (;;) { submit(now()); collect(n++, d_frame, s); draw(d_frame); }
  * i.e. the picture on screen lags the newest seed by the frames in flight.  Measured (monkey, 1920x1080x1024 spp, bench.py
- * "pipelined"): 4 in flight 8,200 Msamples/s against 4,550 one launch at a time and 10,270 for rt_render_device_batch.
+ * "pipelined"): 8,600 Msamples/s with 4 frames in flight and 9,500 with 8, against 4,500 one launch at a time and 10,270 for
+ * rt_render_device_batch.
  * A view's first frame or two (new scene / camera / size / tile spec) run alone: they measure the tiles and sort the schedule,
  * and the host waits for the frames in flight before it rewrites either.  rt_last_kernel_ms does not see pipelined frames;
  * rt_ctx_synchronize waits for them; launches of the other entry points are queued behind them. */
@@ -254,6 +255,10 @@ rt_status rt_frame_depth(rt_ctx *ctx, int32_t depth);
 rt_status rt_frame_submit(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
                           int32_t time_ms, const rt_tile_spec *tiles);
 rt_status rt_frame_collect(rt_ctx *ctx, int32_t frame_num, float *d_frame, void *hip_stream);
+/* Host-buffer form of rt_frame_collect for whole frames (submitted with tiles == NULL), with rt_render's contract: previous_render
+ * (W*H*3 floats) is read (when *frame_num > 0), blended with the oldest submitted frame and overwritten; *frame_num is incremented.
+ * Returns when the frame is in previous_render; the younger frames keep running.  previous_render == NULL discards the frame. */
+rt_status rt_frame_collect_host(rt_ctx *ctx, int32_t *frame_num, float *previous_render);
 /* frames submitted and not collected */
 int32_t rt_frames_pending(const rt_ctx *ctx);
 /* blocks until the frame collected last has been folded into its d_frame (what a host that draws the frame itself waits for:

@@ -80,7 +80,7 @@ ABI_SYMBOLS = [
     "rt_scene_get_info", "rt_render", "rt_render_frames", "rt_render_device", "rt_render_device_batch", "rt_tile_owned_rows", "rt_last_kernel_ms",
     "rt_tile_costs", "rt_partition_tiles", "rt_tiles_copy_device", "rt_max_batch_frames", "rt_peer_access",
     "rt_ctx_synchronize", "rt_render_multi", "rt_render_multi_device", "rt_gather",
-    "rt_frame_submit", "rt_frame_collect", "rt_frames_pending", "rt_frame_wait", "rt_frame_depth",
+    "rt_frame_submit", "rt_frame_collect", "rt_frames_pending", "rt_frame_wait", "rt_frame_depth", "rt_frame_collect_host",
     "rt_to_rgba8_device", "rt_debug_flatten", "rt_debug_read_stats", "rt_debug_eval", "rt_debug_exhaustive", "rt_version",
 ]
 
@@ -176,6 +176,7 @@ def lib():
         L.rt_frames_pending.argtypes = [vp]
         L.rt_frame_wait.argtypes = [vp]
         L.rt_frame_depth.argtypes = [vp, C.c_int32]
+        L.rt_frame_collect_host.argtypes = [vp, C.POINTER(C.c_int32), fp]
     u32p = C.POINTER(C.c_uint32)
     L.rt_tile_costs.argtypes = [vp, u32p, u32p, u32p, C.c_int32, C.POINTER(C.c_int32)]
     L.rt_partition_tiles.argtypes = [u32p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
@@ -715,6 +716,18 @@ def frame_collect(ctx, frame_num, d_frame, stream=None):
     """Fold the oldest submitted frame into the device buffer d_frame as progressive frame frame_num, asynchronously on
     `stream` (rt_frame_collect).  d_frame None: discard the frame."""
     ctx._check(lib().rt_frame_collect(ctx._h, int(frame_num), C.c_void_p(d_frame or 0), C.c_void_p(stream or 0)))
+
+
+def frame_collect_host(ctx, data):
+    """the oldest submitted (whole) frame into data.previous_render, data.frame_num += 1 (rt_frame_collect_host); data None: discard"""
+    if data is None:
+        ctx._check(lib().rt_frame_collect_host(ctx._h, C.byref(C.c_int32(0)), None))
+        return
+    fn = C.c_int32(int(data.frame_num))
+    buf = data.previous_render
+    assert buf.dtype == np.float32 and buf.flags["C_CONTIGUOUS"]
+    ctx._check(lib().rt_frame_collect_host(ctx._h, C.byref(fn), buf.ctypes.data_as(C.POINTER(C.c_float))))
+    data.frame_num = int(fn.value)
 
 
 def frame_wait(ctx):

@@ -1178,6 +1178,33 @@ extern "C" rt_status rt_frame_depth(rt_ctx *ctx, int32_t depth)
     return RT_OK;
 }
 
+namespace { rt_status ensure_frame_buffers(rt_ctx *ctx, size_t bytes); }
+
+/* host-buffer form of rt_frame_collect, with rt_render's contract for previous_render and *frame_num */
+extern "C" rt_status rt_frame_collect_host(rt_ctx *ctx, int32_t *frame_num, float *previous_render)
+{
+    if (!ctx || !frame_num) return set_err(ctx, RT_ERR_INVALID, "null argument");
+    Pipeline &pl = ctx->pipe;
+    if (pl.pending <= 0) return set_err(ctx, RT_ERR_INVALID, "no frame has been submitted");
+    if (!previous_render) return rt_frame_collect(ctx, 0, nullptr, nullptr);          /* discard */
+    if (*frame_num < 0) return set_err(ctx, RT_ERR_INVALID, "bad frame number");
+    FrameSlot &fs = pl.slots[pl.order[0]];
+    if (fs.compact || fs.listed || fs.band_stride != 1) return set_err(ctx, RT_ERR_INVALID, "the host-buffer form collects whole frames (submitted without a tile spec)");
+    RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
+    const size_t bytes = (size_t)fs.width * (size_t)fs.height * 3 * sizeof(float);
+    rt_status st = ensure_frame_buffers(ctx, bytes);
+    if (st != RT_OK) return st;
+    /* everything on the frame's own stream, behind its render kernel; the host waits for that stream only - the younger frames
+     * keep running (a hipDeviceSynchronize, as in rt_render, would wait for them too) */
+    if (*frame_num > 0) RT_HIP(ctx, hipMemcpyAsync(ctx->d_out, previous_render, bytes, hipMemcpyHostToDevice, fs.stream), "copying previous frame");
+    st = rt_frame_collect(ctx, *frame_num, ctx->d_out, fs.stream);
+    if (st != RT_OK) return st;
+    RT_HIP(ctx, hipMemcpyAsync(previous_render, ctx->d_out, bytes, hipMemcpyDeviceToHost, fs.stream), "copying frame to host");
+    RT_HIP(ctx, hipStreamSynchronize(fs.stream), "render kernel");
+    *frame_num += 1;                                   /* src/dispatch.cu:159 */
+    return RT_OK;
+}
+
 extern "C" rt_status rt_frame_wait(rt_ctx *ctx)
 {
     if (!ctx) return RT_ERR_INVALID;

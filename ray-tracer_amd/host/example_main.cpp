@@ -4,7 +4,10 @@
  * progressive frames, write the float->RGBA8 result (src/main.cu:343-371) as a binary PPM or,
  * if the name ends in .png, as a PNG like the reference's images/ directory.
  *
- *   example_main <models_dir> <scene 0..3> <width> <height> <frames> <out.ppm|out.png> [devices, e.g. 0,1,2,3]
+ *   example_main <models_dir> <scene 0..3> <width> <height> <frames> <out.ppm|out.png> [devices, e.g. 0,1,2,3 | pipeN]
+ *
+ * "pipeN" (N = 1..8) instead of a device list: the loop with N frames in flight on one GPU (submit_frame / collect_frame) -
+ * each frame is seeded when it is submitted, as the reference's loop seeds it when it calls render(), and the image is the same.
  *
  * With a device list the same loop runs on a MultiRenderer: every listed GPU renders the bands it owns,
  * the image is the same (a device may be listed twice to rehearse on a one-GPU machine).
@@ -35,7 +38,18 @@ int main(int argc, char **argv)
         VariableRenderData data{0, std::vector<float>((size_t)W * (size_t)H * 3, 0.0f)};
         std::vector<int> times;
         for (int f = 1; f < frames; f++) times.push_back(12345 + f);
-        if (argc > 7) {
+        if (argc > 7 && std::string(argv[7]).compare(0, 4, "pipe") == 0) {
+            const int depth = std::atoi(argv[7] + 4) > 0 ? std::atoi(argv[7] + 4) : 4;
+            Renderer renderer(0);
+            renderer.set_scene(mesh_data);
+            renderer.set_frames_in_flight(depth);
+            int submitted = 0;
+            while (data.frame_num < frames) {
+                while (submitted < frames && renderer.frames_in_flight() < depth) renderer.submit_frame(camera, render_data, 12345 + submitted++);   /* get_time() in the reference */
+                renderer.collect_frame(&data);                                                           /* ... and the window would draw it here */
+            }
+            std::printf("%d frames, %d in flight\n", data.frame_num, depth);
+        } else if (argc > 7) {
             std::vector<int> devices;
             for (const char *p = argv[7]; *p;) { devices.push_back(std::atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; }
             MultiRenderer renderer(devices);

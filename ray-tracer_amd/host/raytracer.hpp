@@ -353,6 +353,27 @@ public:
         check(rt_last_kernel_ms(ctx_, &ms));
         return ms;
     }
+    /* The main loop (src/main.cu:415-431) with frames in flight: submit_frame(get_time()) queues a frame and returns at once,
+     * collect_frame() waits for the OLDEST submitted frame and blends it into data like render() would have.  With `depth`
+     * frames submitted ahead the GPU stays full although every frame is seeded when it is submitted (rt_frame_submit):
+     *     r.set_frames_in_flight(4);
+     *     for (;;) { while (r.frames_in_flight() < 4) r.submit_frame(cam, rd, get_time()); r.collect_frame(&data); draw(data); }
+     * The image after n collected frames is the image of n render() calls with the same seeds. */
+    void set_frames_in_flight(int depth) { check(rt_frame_depth(ctx_, depth)); }
+    int frames_in_flight() const { return rt_frames_pending(ctx_); }
+    void submit_frame(const Camera &cam, const RenderData &rd, int current_time_ms) { check(rt_frame_submit(ctx_, scene_, &cam.c, &rd.c, current_time_ms, nullptr)); }
+    void collect_frame(VariableRenderData *data)
+    {
+        int32_t fn = data->frame_num;
+        check(rt_frame_collect_host(ctx_, &fn, data->previous_render.data()));
+        data->frame_num = fn;
+    }
+    /* the camera moved (src/main.cu:392-407 restarts at frame 0): drop what is in flight */
+    void discard_frames()
+    {
+        int32_t fn = 0;
+        while (rt_frames_pending(ctx_) > 0) check(rt_frame_collect_host(ctx_, &fn, nullptr));
+    }
 
 private:
     rt_ctx *ctx_ = nullptr;
