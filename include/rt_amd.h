@@ -247,8 +247,9 @@ rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, const rt_ca
 #define RT_PIPELINE_DEPTH 8            /* at most */
 #define RT_PIPELINE_DEFAULT_DEPTH 4
 /* How many frames the caller is going to keep in flight (1..RT_PIPELINE_DEPTH; a context starts with RT_PIPELINE_DEFAULT_DEPTH):
- * rt_frame_submit refuses more, and every frame is launched on 1 / depth of the GPU's CUs - `depth` frames side by side, each
- * bound by its work instead of by its longest pixel (alone on the GPU a frame leaves most CUs idle for half its duration).
+ * rt_frame_submit refuses more, and - for scenes whose workgroup has a CU to itself, i.e. a mesh that fills the LDS - every frame is
+ * launched on 1 / depth of the GPU's CUs: `depth` frames side by side, each bound by its work instead of by its longest pixel (alone
+ * on the GPU a frame leaves most CUs idle for half its duration).  Other scenes' launches are full size and share the CUs.
  * Throughput grows with the depth, and so does a frame's latency (depth x the time per frame).  depth 1 is rt_render_device
  * with a plane in between.  Only while no frame is in flight (RT_ERR_BUSY otherwise). */
 rt_status rt_frame_depth(rt_ctx *ctx, int32_t depth);

@@ -165,6 +165,7 @@ struct rt_ctx {
     int hit_low = RT_DEF_HIT_LOW, mix_break = RT_DEF_MIX_BREAK;   /* RT_AMD_HIT_LOW, RT_AMD_MIX_BREAK (0 = that rule off) */
     int shade_batch = RT_DEF_SHADE_BATCH;        /* lanes; RT_AMD_SHADE_BATCH (1..64) */
     Pipeline pipe;
+    int pipe_share = 2;                          /* RT_AMD_PIPE_SHARE: pipelined frames run on 1 / depth of the CUs - 0 never, 1 always, 2 when a workgroup fills a CU */
     int multi_careful = 0;                       /* RT_AMD_MULTI_CAREFUL=1: rt_render_multi_device waits on the host after every phase (diagnosis) */
 };
 
@@ -352,6 +353,7 @@ extern "C" rt_status rt_ctx_create(int32_t device, rt_ctx **out)
     if (const char *e = getenv("RT_AMD_HIT_LOW")) { int v = atoi(e); if (v >= 0 && v <= 65) ctx->hit_low = v; }
     if (const char *e = getenv("RT_AMD_MIX_BREAK")) { int v = atoi(e); if (v >= 0 && v <= 130) ctx->mix_break = v; }
     if (const char *e = getenv("RT_AMD_SHADE_BATCH")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->shade_batch = v; }
+    if (const char *e = getenv("RT_AMD_PIPE_SHARE")) { int v = atoi(e); if (v >= 0 && v <= 2) ctx->pipe_share = v; }
     if (const char *e = getenv("RT_AMD_MULTI_CAREFUL")) ctx->multi_careful = atoi(e) != 0;
     if (const char *e = getenv("RT_AMD_READY_BREAK")) { int v = atoi(e); if (v >= 1 && v <= 65) ctx->ready_break = v; }
     if (hipMalloc((void **)&ctx->tile_counter, 1024) != hipSuccess ||
@@ -1042,9 +1044,11 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
             /* A pipelined frame gets its share of the CUs, not all of them: a frame alone on the GPU is as long as its longest
              * pixel and leaves most CUs idle (or held by a workgroup with one busy wave) for half of that time; on 1 / depth of
              * the CUs the same frame is bound by its work instead, and `depth` of them fill the GPU (measured, monkey 1080p
-             * 1024 spp, 4 in flight: 286 ms per frame with full-size launches, 242 with quarter-size ones). */
+             * 1024 spp, 4 in flight: 286 ms per frame with full-size launches, 242 with quarter-size ones).
+             * Only where a workgroup has its CU to itself (a mesh that fills the LDS): smaller workgroups of several launches share
+             * CUs anyway, and full-size launches are then the faster ones (three-sphere 61.7 against 65.1 ms, cube 112.8 against 118.0). */
             const int d = ctx->pipe.depth;
-            blocks = (blocks + d - 1) / d;
+            if (ctx->pipe_share == 1 || (ctx->pipe_share == 2 && scene->blocks_per_cu == 1)) blocks = (blocks + d - 1) / d;
         }
         RT_HIP(ctx, hipMemsetAsync(a.tile_counter, 0, 512, stream), "clearing tile counter");
         RT_HIP(ctx, rt_launch_render(&a, scene->flat.has_mesh ? 1 : 0, scene->scene_in_lds, scene->threads, blocks, scene->lds_bytes, stream), "launching render kernel");
