@@ -1095,8 +1095,8 @@ extern "C" rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, 
 /* ---- pipelined frames --------------------------------------------------------------------------------------------------- */
 static rt_status init_slot(rt_ctx *ctx, FrameSlot &fs)
 {
-    if (fs.stream) return RT_OK;
-    {
+    /* (each member on its own: a call that failed half-way is finished by the next one) */
+    if (!fs.stream) {
         /* Frames only overlap if their streams sit on different hardware queues.  The runtime keeps a pool of them per stream
          * priority (four each by default, GPU_MAX_HW_QUEUES) and the caller's own streams - the null stream, PyTorch's - already
          * live in the normal-priority pool: a fourth frame's stream would share a queue there and run behind its neighbour
@@ -1110,10 +1110,10 @@ static rt_status init_slot(rt_ctx *ctx, FrameSlot &fs)
         else
             RT_HIP(ctx, hipStreamCreateWithFlags(&fs.stream, hipStreamNonBlocking), "creating a pipelined frame's stream");
     }
-    RT_HIP(ctx, hipMalloc((void **)&fs.counter, 1024), "allocating a pipelined frame's ticket counter");
-    RT_HIP(ctx, hipEventCreateWithFlags(&fs.ev_done, hipEventDisableTiming), "creating a pipelined frame's event");
-    RT_HIP(ctx, hipEventCreateWithFlags(&fs.ev_free, hipEventDisableTiming), "creating a pipelined frame's event");
-    RT_HIP(ctx, hipEventCreateWithFlags(&fs.ev_call, hipEventDisableTiming), "creating a pipelined frame's event");
+    if (!fs.counter) RT_HIP(ctx, hipMalloc((void **)&fs.counter, 1024), "allocating a pipelined frame's ticket counter");
+    if (!fs.ev_done) RT_HIP(ctx, hipEventCreateWithFlags(&fs.ev_done, hipEventDisableTiming), "creating a pipelined frame's event");
+    if (!fs.ev_free) RT_HIP(ctx, hipEventCreateWithFlags(&fs.ev_free, hipEventDisableTiming), "creating a pipelined frame's event");
+    if (!fs.ev_call) RT_HIP(ctx, hipEventCreateWithFlags(&fs.ev_call, hipEventDisableTiming), "creating a pipelined frame's event");
     return RT_OK;
 }
 
