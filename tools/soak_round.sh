@@ -8,3 +8,4 @@ timeout -k 10 400 python tests/soak/soak_parity.py 520000 600 bigmesh > $O/soak_
 RT_SOAK_SIZE=640x360x32 timeout -k 10 300 python tests/soak/soak_parity.py 530000 48 config > $O/soak_large_frames.txt 2>&1; tail -1 $O/soak_large_frames.txt
 timeout -k 10 500 python tests/soak/soak_partition.py 540000 4000 > $O/soak_partition.txt 2>&1; tail -1 $O/soak_partition.txt
 python __graft_entry__.py smoke 2>&1 | tail -1
+timeout -k 10 600 python tests/soak/soak_pipeline.py 550000 5000 > $O/soak_pipeline.txt 2>&1; tail -1 $O/soak_pipeline.txt
