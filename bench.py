@@ -449,7 +449,8 @@ def main():
             el = time.perf_counter() - t0
             return {"frames_in_flight": depth, "steps": n_frames, "value": W * H * spp * n_frames / el / 1e6, "unit": "Msamples/s",
                     "ms_per_step": el / n_frames * 1e3, "frames_per_s": n_frames / el}, pf
-        p4, pf = run_pipelined(rt.PIPELINE_DEFAULT_DEPTH, args.steps)
+        # (never a deeper pipeline than there are steps: every frame runs on 1 / depth of the CUs, so a depth the run cannot fill idles the rest)
+        p4, pf = run_pipelined(max(1, min(rt.PIPELINE_DEFAULT_DEPTH, args.steps)), args.steps)
         pipelined = dict(p4)
         pipelined["equals_batched"] = bool(frame is not None and torch.equal(pf.view(torch.int32), frame.contiguous().view(torch.int32)))
         del pf
