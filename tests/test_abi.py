@@ -57,3 +57,22 @@ def test_no_gpu_means_failure_not_fallback(rt):
         pytest.skip("a GPU is present")
     with pytest.raises(rt.RayTracerError, match="no CPU fallback"):
         rt.Context(0)
+
+
+def test_pipelined_entry_points_refuse_a_null_context(rt):
+    """no GPU needed: the frames-in-flight entry points check their context before they touch HIP"""
+    import ctypes as C
+    L = rt.lib()
+    assert L.rt_frame_submit(None, None, None, None, 0, None) == rt.RT_ERR_INVALID
+    assert L.rt_frame_collect(None, 0, None, None) == rt.RT_ERR_INVALID
+    assert L.rt_frame_collect_host(None, C.byref(C.c_int32(0)), None) == rt.RT_ERR_INVALID
+    assert L.rt_frame_wait(None) == rt.RT_ERR_INVALID
+    assert L.rt_frame_depth(None, 4) == rt.RT_ERR_INVALID
+    assert L.rt_frames_pending(None) == 0
+    assert (rt.PIPELINE_DEFAULT_DEPTH, rt.PIPELINE_DEPTH) == (4, 8)
+    # the header's macros say the same
+    import os, re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rt_amd.h")).read()
+    assert int(re.search(r"#define RT_PIPELINE_DEPTH (\d+)", hdr).group(1)) == rt.PIPELINE_DEPTH
+    assert int(re.search(r"#define RT_PIPELINE_DEFAULT_DEPTH (\d+)", hdr).group(1)) == rt.PIPELINE_DEFAULT_DEPTH
+    assert int(re.search(r"RT_ERR_BUSY = (\d+)", hdr).group(1)) == rt.RT_ERR_BUSY
