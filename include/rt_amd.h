@@ -230,11 +230,14 @@ rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, const rt_ca
  *   rt_frame_submit   queues ONE frame seeded with time_ms on a stream of the context's own (up to rt_frame_depth submitted
  *                     and not yet collected; RT_ERR_BUSY beyond).  The frame's per-pixel means go to a plane the context keeps;
  *                     nothing the caller owns is touched.  Frames in flight run side by side on the GPU.
- *   rt_frame_collect  takes the OLDEST submitted frame: on `hip_stream`, behind that frame's render kernel, folds it into d_frame
- *                     as progressive frame `frame_num` ((c + prev * frame_num) / (frame_num + 1), src/raytracer.cu:109-112; d_frame
- *                     has the layout of rt_render_device's d_out for the tile spec the frame was submitted with, and is ignored
- *                     as input when frame_num == 0).  Asynchronous like rt_render_device.  d_frame == NULL discards the frame
- *                     (the camera moved: the reference restarts at frame 0, src/main.cu:392-407).
+ *   rt_frame_collect  takes the OLDEST submitted frame and folds it into d_frame as progressive frame `frame_num`
+ *                     ((c + prev * frame_num) / (frame_num + 1), src/raytracer.cu:109-112; d_frame has the layout of
+ *                     rt_render_device's d_out for the tile spec the frame was submitted with, and is ignored as input when
+ *                     frame_num == 0).  Asynchronous: the fold runs behind the frame's render kernel and behind whatever the caller
+ *                     has queued on `hip_stream` so far, and work queued on `hip_stream` afterwards sees the folded frame.
+ *                     d_frame == NULL discards the frame (the camera moved: the reference restarts at frame 0,
+ *                     src/main.cu:392-407).  Frames submitted with a tile LIST must be collected (or discarded) before frames of
+ *                     another list are submitted (RT_ERR_BUSY).
  * Frames are collected in submission order, and the image after collecting frames 0..k is bit-identical to k + 1 calls of
  * rt_render_device with the same seeds (tests/test_gpu_pipeline.py).  The loop becomes
  *     submit(t0); for (;;) { submit(now()); collect(n++, d_frame, s); draw(d_frame); }
@@ -250,8 +253,10 @@ rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, const rt_ca
  * rt_frame_submit refuses more, and - for scenes whose workgroup has a CU to itself, i.e. a mesh that fills the LDS - every frame is
  * launched on 1 / depth of the GPU's CUs: `depth` frames side by side, each bound by its work instead of by its longest pixel (alone
  * on the GPU a frame leaves most CUs idle for half its duration).  Other scenes' launches are full size and share the CUs.
- * Throughput grows with the depth, and so does a frame's latency (depth x the time per frame).  depth 1 is rt_render_device
- * with a plane in between.  Only while no frame is in flight (RT_ERR_BUSY otherwise). */
+ * Throughput grows with the depth, and so does a frame's latency (depth x the time per frame); 2, 4 and 8 are the useful values
+ * (the depths in between measure no better than the next lower one).  depth 1 is rt_render_device with a plane in between.
+ * The context keeps one plane (12 bytes per pixel of the launch's layout) per frame in flight.  Only while no frame is in flight
+ * (RT_ERR_BUSY otherwise). */
 rt_status rt_frame_depth(rt_ctx *ctx, int32_t depth);
 rt_status rt_frame_submit(rt_ctx *ctx, const rt_scene *scene, const rt_camera *cam, const rt_render_settings *rs,
                           int32_t time_ms, const rt_tile_spec *tiles);
