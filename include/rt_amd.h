@@ -122,7 +122,7 @@ rt_status rt_obj_from_arrays(const float *vertices, int32_t num_vertices, const 
                              const int32_t *face_arity, int32_t num_faces, rt_obj **out);
 void rt_obj_get_vertices(const rt_obj *o, float *out /* num_vertices*3 */);
 int32_t rt_obj_num_triangles(const rt_obj *o);                       /* after the quad split; -1 if a face is not 3/4-sided */
-rt_status rt_obj_get_triangles(const rt_obj *o, float *out /* num_triangles*9 */);
+rt_status rt_obj_get_triangles(const rt_obj *o, float *out /* num_triangles*9 */);     /* RT_ERR_INVALID: a face names a vertex the file does not have */
 
 /* ---- camera: src/camera.cu:12-21 (DeviceCamData) and :34-108 (Camera) -------------------- */
 typedef struct rt_camera {

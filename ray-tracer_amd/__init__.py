@@ -364,7 +364,9 @@ class ObjFileMesh:
         if n < 0:
             raise UnsupportedMeshError("Only triangle or quad meshes are supported.\n")
         out = np.empty((n, 9), np.float32)
-        lib().rt_obj_get_triangles(self._h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        st = lib().rt_obj_get_triangles(self._h, out.ctypes.data_as(C.POINTER(C.c_float)))
+        if st != RT_OK:
+            raise ValueError("face references a missing vertex")
         return out
 
     def __del__(self):

@@ -623,7 +623,13 @@ extern "C" int32_t rt_obj_num_triangles(const rt_obj *o)
 
 extern "C" rt_status rt_obj_get_triangles(const rt_obj *o, float *out)
 {
+    if (!o || !out) return RT_ERR_INVALID;
     if (rt_obj_num_triangles(o) < 0) return RT_ERR_UNSUPPORTED;
+    /* a face may name a vertex the file does not have (index 0, a negative one, one past the end): the loader keeps what the file
+     * says, like the reference's (src/obj_read.cu:121-147), and the uses check (rt_scene_add_obj_mesh does too) */
+    for (const auto &f : o->faces)
+        for (int vi : f)
+            if (vi < 0 || (size_t)vi >= o->vx.size()) return RT_ERR_INVALID;
     size_t k = 0;
     auto put = [&](int vi) { out[k++] = o->vx[(size_t)vi]; out[k++] = o->vy[(size_t)vi]; out[k++] = o->vz[(size_t)vi]; };
     for (const auto &f : o->faces) {
