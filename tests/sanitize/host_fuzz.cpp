@@ -192,6 +192,50 @@ static void fuzz_texture_file(const std::string &dir, int id)
     std::remove(path.c_str());
 }
 
+/* rt_obj_from_arrays with indices that may miss the vertex array, and meshes whose triangles all coincide (a BVH that cannot split
+ * them: the 1,023-triangles-per-leaf limit must come back as an error) */
+static void fuzz_arrays_and_big_leaves()
+{
+    const int nv = irand(0, 12), nf = irand(0, 20);
+    std::vector<float> v((size_t)nv * 3 + 3);
+    for (float &x : v) x = u01() < 0.9 ? (float)((u01() - 0.5) * 4) : odd_float();
+    std::vector<int32_t> arity((size_t)nf + 1), idx;
+    for (int f = 0; f < nf; f++) {
+        arity[(size_t)f] = irand(0, 10) ? irand(3, 4) : irand(0, 6);
+        for (int j = 0; j < arity[(size_t)f]; j++) idx.push_back(irand(0, 12) ? irand(0, nv > 0 ? nv - 1 : 0) : irand(-3, nv + 3));
+    }
+    idx.push_back(0);
+    rt_obj *o = nullptr;
+    rt_material m;
+    float c[3] = {0.2f, 0.3f, 0.4f};
+    rt_material_standard(&m, c, 0.1f);
+    rt_scene_builder *b = nullptr;
+    if (rt_scene_builder_create(&b) != RT_OK) std::abort();
+    if (rt_obj_from_arrays(v.data(), nv, idx.data(), arity.data(), nf, &o) == RT_OK && o) {
+        const int nt = rt_obj_num_triangles(o);
+        if (nt >= 0) { std::vector<float> tri((size_t)nt * 9 + 9); (void)rt_obj_get_triangles(o, tri.data()); }
+        (void)rt_scene_add_obj_mesh(b, o, &m);
+    }
+    if (irand(0, 3) == 0) {
+        const int n = irand(900, 2500);
+        std::vector<float> tris((size_t)n * 9);
+        float base[9];
+        for (float &x : base) x = (float)(u01() - 0.5);
+        const bool jitter = irand(0, 1);
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 9; k++) tris[(size_t)i * 9 + k] = base[k] + (jitter ? (float)(u01() * 1e-6) : 0.0f);
+        (void)rt_scene_add_mesh(b, tris.data(), n, &m);
+    }
+    rt_flat_view fv;
+    std::memset(&fv, 0, sizeof fv);
+    if (rt_debug_flatten(b, &fv) == RT_OK) {
+        volatile float sink = 0;
+        for (long long i = 0; i < (long long)fv.blob_f4 * 4; i += 11) sink = sink + fv.blob[i];
+    }
+    rt_scene_builder_destroy(b);
+    rt_obj_destroy(o);
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 4) { std::fprintf(stderr, "usage: %s <scratch dir> <seed> <cases>\n", argv[0]); return 2; }
@@ -201,6 +245,7 @@ int main(int argc, char **argv)
     for (int i = 0; i < cases; i++) {
         fuzz_obj_and_scene(dir, i);
         if (i % 4 == 0) fuzz_texture_file(dir, i);
+        if (i % 3 == 0) fuzz_arrays_and_big_leaves();
         rt_camera cam;
         rt_camera_default(irand(1, 4000), irand(1, 3000), &cam);
         float pos[3] = {odd_float(), (float)u01(), -1.0f};
