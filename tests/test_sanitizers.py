@@ -66,3 +66,57 @@ def test_gpu_free_entry_points_of_the_c_abi_under_asan_and_ubsan(tmp_path):
     for seed in (1, 2):
         r = subprocess.run([exe, str(seed), "3000"], capture_output=True, text=True, timeout=300, env=env)
         assert r.returncode == 0 and "sanitizers silent" in r.stdout, (seed, (r.stderr or r.stdout)[-3000:])
+
+
+_ORACLE_SCRIPT = r"""
+import sys, importlib
+sys.path.insert(0, ROOT); sys.path.insert(0, ROOT + "/tests")
+from oracle import binding as B
+B._LIB_PATH = LIB
+scenes = importlib.import_module("ray-tracer_amd.scenes")
+from test_gpu_parity import _random_scene
+import numpy as np
+F = np.float32
+def cam(W, H):
+    # any camera will do here: the reference's default pose written out (no product library in this process)
+    return [0.0, 0.0, -1.0, -0.5, 0.5 * H / W, 0.0, 1.0 / W, 0.0, 0.0, 0.0, -1.0 / W, 0.0]
+models = scenes.models_dir()
+n = 0
+for name in ["monkey", "cube", "three_sphere", "reference_scene0", "reference_scene2", "reference_scene3", "reference_scene4"]:
+    objs, sky = scenes.CONFIG_SCENES[name]()
+    o = B.Scene(objs, B.MATH_DET, models)
+    prev = None
+    for f in range(2):
+        prev = o.render(cam(45, 31), 45, 31, 2, 6, sky, time_ms=99 + f, frame_num=f, prev=prev)
+    n += 1
+for seed in range(40):
+    objs, sky = _random_scene(seed)
+    B.Scene(objs, B.MATH_DET if seed % 2 else B.MATH_LIBM, models).render(cam(33, 27), 33, 27, 2, 5, sky, time_ms=seed)
+    n += 1
+print("oracle: %d scenes rendered, sanitizers silent" % n)
+"""
+
+
+def test_oracle_under_asan_and_ubsan(tmp_path):
+    """the checker itself: oracle/rt_oracle.c built with -fsanitize=address,undefined renders config and random scenes (meshes, textures,
+    refraction, both math modes) in a child process with the sanitizer runtimes preloaded"""
+    import sys
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    asan = subprocess.run([gcc, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    ubsan = subprocess.run([gcc, "-print-file-name=libubsan.so"], capture_output=True, text=True).stdout.strip()
+    if not (os.path.isabs(asan) and os.path.exists(asan) and os.path.isabs(ubsan) and os.path.exists(ubsan)):
+        pytest.skip("no sanitizer runtimes")
+    lib = str(tmp_path / "librt_oracle_asan.so")
+    fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read().split() else []
+    cmd = [gcc, "-std=gnu11", "-O1", "-g", "-ffp-contract=off"] + fma + ["-fno-fast-math", "-fno-builtin-tanf", "-fno-builtin-sinf", "-fno-builtin-cosf",
+           "-fno-builtin-logf", "-fPIC", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-shared", "-o", lib,
+           os.path.join(ROOT, "oracle", "rt_oracle.c"), "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    script = tmp_path / "run.py"
+    script.write_text("ROOT = %r\nLIB = %r\n" % (ROOT, lib) + _ORACLE_SCRIPT)
+    env = dict(os.environ, LD_PRELOAD=asan + ":" + ubsan, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "sanitizers silent" in r.stdout, (r.stderr or r.stdout)[-3000:]
