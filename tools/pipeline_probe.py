@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--limit", type=int, default=8)
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--depths", default="1,2,3,4,6,8")
+    ap.add_argument("--host", action="store_true", help="host-buffer form (rt_frame_collect_host: upload of the previous image, fold, download per frame)")
     args = ap.parse_args()
     import torch
     rt = importlib.import_module("ray-tracer_amd")
@@ -45,8 +46,20 @@ def main():
         rt.frame_submit(ctx, scene, cam, rd, 777 + i)
         rt.frame_collect(ctx, i, fr.data_ptr(), stream=st)
     torch.cuda.synchronize()
+    data = rt.VariableRenderData(args.width, args.height)
     for depth in [int(x) for x in args.depths.split(",")]:
         rt.frame_depth(ctx, depth)
+        if args.host:
+            data.frame_num = 0
+            t0 = time.perf_counter()
+            sent = 0
+            while data.frame_num < args.frames:
+                while sent < args.frames and rt.frames_pending(ctx) < depth:
+                    rt.frame_submit(ctx, scene, cam, rd, 12345 + sent); sent += 1
+                rt.frame_collect_host(ctx, data)
+            el = time.perf_counter() - t0
+            print("in flight %d  %8.1f ms per frame  %8.0f Msamples/s   (host buffers: 2 x %.1f MB over PCIe per frame)" % (depth, el / args.frames * 1e3, samples / el / 1e6, data.previous_render.nbytes / 1e6), flush=True)
+            continue
         t0 = time.perf_counter()
         n = 0
         for i in range(args.frames):
