@@ -51,11 +51,21 @@ RT_RNG_HD float rt_u01(uint32_t r)
     return (float)((double)r * RT_RNG_INV_2P32M1);
 }
 
-/* (float)(((double)u - 0.5) * 2 * (double)0.001f) with u = rt_u01(r) */
+/* (float)(((double)u - 0.5) * 2 * (double)0.001f) with u = rt_u01(r).
+ * As ONE binary32 fused multiply-add (round 4): K = 2 * 0.001f is a binary32 number (a doubled one) and so is K / 2 = 0.001f, and
+ * (u - 0.5) * K = u * K - K / 2 as real numbers; the reference's expression rounds that value to binary32 at the end (its binary64
+ * steps in between are exact or err far below a binary32 half-ulp), and fmaf(u, K, -K / 2) rounds the exact value once.  The same
+ * function: tests/test_rng_exhaustive.py compares it with the reference's expression for all 2^32 values of r.  One v_fma_f32
+ * instead of v_cvt_f64_f32 + v_add_f64 + v_mul_f64 + v_cvt_f32_f64, three times per generated ray.  RT_RNG_JITTER_F64 keeps the
+ * binary64 form (A/B builds). */
 RT_RNG_HD float rt_jitter(uint32_t r)
 {
+#ifdef RT_RNG_JITTER_F64
     const double K = 2.0 * (double)0.001f;
     return (float)(((double)rt_u01(r) - 0.5) * K);
+#else
+    return __builtin_fmaf(rt_u01(r), 2.0f * 0.001f, -0.001f);
+#endif
 }
 
 /* (float)(2 * 3.14159 * (double)u) with u = rt_u01(r) */
