@@ -68,7 +68,10 @@ RT_RNG_HD float rt_jitter(uint32_t r)
 #endif
 }
 
-/* (float)(2 * 3.14159 * (double)u) with u = rt_u01(r) */
+/* (float)(2 * 3.14159 * (double)u) with u = rt_u01(r).
+ * (Round 4 also tried this one in binary32: fmaf(u, CH, u * CL) with CH + CL = 6.28318 split into two binary32 numbers is the same
+ * function for all 2^32 values of r - checked exhaustively - and two instructions instead of three, but the kernels with a mesh got
+ * 0.4 % slower with it and the others no faster than with the jitter alone: profiles/r04/experiments/rng_binary32_forms.txt.) */
 RT_RNG_HD float rt_theta(uint32_t r)
 {
     return (float)(6.28318 * (double)rt_u01(r));
