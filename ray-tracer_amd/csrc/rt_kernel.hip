@@ -487,6 +487,8 @@ __global__ void rt_eval_kernel(int op, const uint32_t *in, uint32_t *out, int n)
         case 10: r = (float)rt_pow5((double)x); break;
         case 11: r = rt_rcp_in_range(x) ? rt_rcp_short(x) : 1.0f / x; break;       /* per lane what rt_rcp / rt_sqrt do per wave */
         case 12: r = rt_sqrt_in_range(x) ? rt_sqrt_short(x) : sqrtf(x); break;
+        case 13: r = rt_logf_0_1(rt_u01(u)); break;                                  /* the Box-Muller calls on a hash output */
+        case 14: r = rt_cosf_0_2pi(rt_theta(u)); break;
         default: break;
     }
     out[i] = __float_as_uint(r);

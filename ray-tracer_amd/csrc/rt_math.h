@@ -157,6 +157,51 @@ RT_HD int rt__rem_pio2(float x, float *r_out)
     }
 }
 
+/* ---- the two calls of the Box-Muller transform, on the arguments it can produce (round 4) ------------------
+ * normal_num (src/utils.cu:234-239) takes the logarithm of u = rt_u01(r) - a binary32 number in [0, 1], zero or normal, never negative,
+ * NaN or infinite - and the cosine of theta = rt_theta(r) in [0, 6.28318].  rt_logf and rt_cosf spend a good part of their
+ * instructions telling such arguments from the others (on the GPU: nested exec-mask branches, ~12 scalar instructions per call, and
+ * the binary64 reduction for huge angles sits in the instruction stream).  These two are rt_logf and rt_cosf WITHOUT the cases that
+ * cannot occur - every operation that remains is the same operation in the same order - and tests/test_rng_exhaustive.py checks
+ * rt_logf_0_1(rt_u01(r)) == rt_logf(rt_u01(r)) and rt_cosf_0_2pi(rt_theta(r)) == rt_cosf(rt_theta(r)) for every one of the 2^32
+ * values of r.  (Below pi / 4 rt_cosf skips the reduction; here it runs and finds n = 0, r = x: x * (2 / pi) rounds to 0 and
+ * fma(-0, P, x) is x.)  The oracle keeps calling rt_logf and rt_cosf. */
+RT_HD float rt_logf_0_1(float x)
+{
+    const float LN2_HI = 0.693145751953125f;
+    const float LN2_LO = 1.428606765330187e-06f;
+    uint32_t ix = rt_f2u(x);
+    if (ix == 0u) return rt_u2f(0xff800000u);                /* log(0) = -inf */
+    int k = (int)(ix >> 23) - 127;
+    uint32_t m = ix & 0x007fffffu;
+    uint32_t mb;
+    if (m >= 0x003504f4u) { mb = m | 0x3f000000u; k += 1; }
+    else                  { mb = m | 0x3f800000u; }
+    float f = rt_u2f(mb) - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float R = z * RT_FMAF(z, RT_FMAF(z, RT_FMAF(z, 0.2222222222222222f, 0.2857142857142857f), 0.4f), 0.6666666666666666f);
+    float hfsq = 0.5f * f * f;
+    float dk = (float)k;
+    float t = RT_FMAF(s, hfsq + R, dk * LN2_LO);
+    return RT_FMAF(dk, LN2_HI, f - (hfsq - t));
+}
+
+RT_HD float rt_cosf_0_2pi(float x)
+{
+    const float TWO_OVER_PI = 0.6366197466850281f;
+    const float P1 = 1.570556640625f, P2 = 0.0002396702766418457f, P3 = 1.5890691429376602e-08f, P4 = 2.5633440682570896e-12f;
+    const float MAGIC = 12582912.0f;
+    float fn = RT_FMAF(x, TWO_OVER_PI, MAGIC) - MAGIC;
+    float r = RT_FMAF(-fn, P1, x);
+    r = RT_FMAF(-fn, P2, r);
+    r = RT_FMAF(-fn, P3, r);
+    r = RT_FMAF(-fn, P4, r);
+    int n = (int)fn & 3;
+    float c = (n & 1) ? rt__sin_k(r) : rt__cos_k(r);
+    return ((n + 1) & 2) ? -c : c;
+}
+
 RT_HD float rt_sinf(float x)
 {
     float r;

@@ -86,8 +86,14 @@ __device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ float normal_num(uint32_t &state)
 {
     float theta = rt_theta(rt_pcg_next(&state));
+#ifdef RT_GENERIC_BOX_MULLER       /* (A/B builds: the general-purpose log and cos) */
     float rho = rt_sqrt(-2.0f * rt_logf(rt_u01(rt_pcg_next(&state))));
     return rho * rt_cosf(theta);
+#else
+    /* log on [0, 1] and cos on [0, 6.28318]: rt_logf / rt_cosf without the cases these arguments cannot be (rt_math.h) */
+    float rho = rt_sqrt(-2.0f * rt_logf_0_1(rt_u01(rt_pcg_next(&state))));
+    return rho * rt_cosf_0_2pi(theta);
+#endif
 }
 
 /* the scene sections (LDS, or global memory for what of a large scene does not fit a CU's LDS) */

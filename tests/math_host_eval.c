@@ -25,6 +25,9 @@ void host_eval(int op, const uint32_t *in, uint32_t *out, int n)
             case 8: r = sqrtf(x); break;
             case 9: r = 1.0f / x; break;
             case 10: r = (float)rt_pow5((double)x); break;
+            /* 13 / 14 on the device are rt_logf_0_1 / rt_cosf_0_2pi; the host answers with the GENERAL functions: the same values */
+            case 13: r = rt_logf(rt_u01(u)); break;
+            case 14: r = rt_cosf(rt_theta(u)); break;
         }
         memcpy(&out[i], &r, 4);
     }

@@ -50,6 +50,12 @@ CASES = [
     (8, "sqrtf", lambda r: np.concatenate([_float_inputs(r, 0, 4, 500000), r.integers(0, 0x7f800000, 500000, dtype=np.uint64).astype(np.uint32)])),
     (9, "1/x", lambda r: np.concatenate([_float_inputs(r, -4, 4, 500000), r.integers(0, 2**32, 500000, dtype=np.uint64).astype(np.uint32)])),
     (10, "rt_pow5", lambda r: _float_inputs(r, 0, 1.2, 300000)),
+    # the Box-Muller calls: the device evaluates rt_logf_0_1 / rt_cosf_0_2pi (log and cos without the cases a draw cannot produce), the
+    # host the general rt_logf / rt_cosf on the same hash outputs (all 2^32 of them on the host alone: tests/test_rng_exhaustive.py)
+    (13, "log of a draw", lambda r: np.concatenate([r.integers(0, 2**32, 4000000, dtype=np.uint64).astype(np.uint32), np.arange(0, 4096, dtype=np.uint32),
+                                                    np.array([0x7fffffff, 0x80000000, 0xfffffffe, 0xffffffff], np.uint32)])),
+    (14, "cos of a draw", lambda r: np.concatenate([r.integers(0, 2**32, 4000000, dtype=np.uint64).astype(np.uint32), np.arange(0, 4096, dtype=np.uint32),
+                                                    np.array([0x1fffffff, 0x20000000, 0x3fffffff, 0x40000000, 0x7fffffff, 0x80000000, 0xfffffffe, 0xffffffff], np.uint32)])),
 ]
 
 

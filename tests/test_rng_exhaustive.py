@@ -17,7 +17,7 @@ def test_rng_forms_match_the_reference_expressions_for_all_inputs(tmp_path):
     stride = os.environ.get("RT_RNG_STRIDE", "1")
     out = subprocess.run([exe, str(threads), stride], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout
-    assert out.stdout.strip() == "mismatches u01=0 jitter=0 theta=0"
+    assert out.stdout.strip() == "mismatches u01=0 jitter=0 theta=0 log=0 cos=0"
 
 
 def test_oracle_stream_equals_rt_rng(orc):
