@@ -39,13 +39,25 @@ __device__ __forceinline__ float rt_rcp_short(float x)
     const float y = __builtin_amdgcn_rcpf(x);
     return __builtin_fmaf(y, __builtin_fmaf(-x, y, 1.0f), y);
 }
+/* sqrtf(x) for x in the range above, from the reciprocal square root: s0 = x * rsq(x) is the root to ~2 ulp, and one step
+ * s0 + (x - s0^2) * (rsq / 2) with the residual as an fma lands on the correctly rounded value for EVERY binary32 from 2^-102 up
+ * (tools/ubench/rsq_forms.hip on the device; tests/test_gpu_math.py's exhaustive test runs this very function against sqrtf over
+ * all 2^32 patterns).  Five instructions - v_rsq_f32, two multiplies, two fma - where round 4's first form (v_sqrt_f32, then a
+ * residual test of the neighbours one ulp down and up: RT_SQRT_BY_NEIGHBOURS keeps it for A/B builds) took nine, four of them
+ * compares and selects. */
 __device__ __forceinline__ float rt_sqrt_short(float x)
 {
+#ifdef RT_SQRT_BY_NEIGHBOURS
     float s = __builtin_amdgcn_sqrtf(x);
     const float dn = __uint_as_float(__float_as_uint(s) - 1u), up = __uint_as_float(__float_as_uint(s) + 1u);
     const float rdn = __builtin_fmaf(-dn, s, x), rup = __builtin_fmaf(-up, s, x);
     s = rdn <= 0.0f ? dn : s;
     return rup > 0.0f ? up : s;
+#else
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s0 = x * y, h = 0.5f * y;
+    return __builtin_fmaf(__builtin_fmaf(-s0, s0, x), h, s0);
+#endif
 }
 __device__ __forceinline__ float rt_sqrt(float x)       /* == sqrtf(x) */
 {
