@@ -375,7 +375,7 @@ rt_status rt_debug_flatten(rt_scene_builder *b, rt_flat_view *out);
 /* evaluates one function of the shared math / RNG headers ON THE DEVICE, element-wise, on raw
  * 32-bit patterns (host pointers).  op: 0 rt_logf, 1 rt_cosf, 2 rt_sinf, 3 rt_asinf, 4 rt_acosf,
  * 5 rt_u01, 6 rt_jitter, 7 rt_theta (5-7 take the uint32 hash output), 8 sqrtf, 9 1.0f/x,
- * 10 (float)rt_pow5, 11 / 12 the guarded short 1 / x and sqrt, 13 rt_logf_0_1(rt_u01(hash)), 14 rt_cosf_0_2pi(rt_theta(hash)):
+ * 10 (float)rt_pow5, 11 / 12 the guarded short 1 / x and sqrt, 13 / 15 rt_logf_0_1(rt_u01(hash)) with the short / the operator's division, 14 rt_cosf_0_2pi(rt_theta(hash)):
  * the Box-Muller calls on a hash output */
 rt_status rt_debug_eval(rt_ctx *ctx, int32_t op, const uint32_t *in, uint32_t *out, int32_t n);
 /* test hook: the device code's short 1 / x and sqrt(x) against the compiler's IEEE expansions for all 2^32 inputs; out4 = {differing

@@ -1258,7 +1258,7 @@ extern "C" rt_status rt_tiles_copy_device(rt_ctx *ctx, float *d_compact, float *
  * and returned as raw 32-bit patterns in host memory */
 extern "C" rt_status rt_debug_eval(rt_ctx *ctx, int32_t op, const uint32_t *in, uint32_t *out, int32_t n)
 {
-    if (!ctx || !in || !out || n <= 0 || op < 0 || op > 14) return set_err(ctx, RT_ERR_INVALID, "bad argument");
+    if (!ctx || !in || !out || n <= 0 || op < 0 || op > 15) return set_err(ctx, RT_ERR_INVALID, "bad argument");
     RT_HIP(ctx, hipSetDevice(ctx->device), "selecting device");
     uint32_t *d_in = nullptr, *d_out = nullptr;
     RT_HIP(ctx, hipMalloc((void **)&d_in, (size_t)n * 4), "allocating eval input");

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : (HAS_MESH ? RT_SMALL_WG_WAVES 
                                         : (n_hit >= a.shade_batch || !others))) {
                 if (p.mode == M_SHADE) {
                     RT_STAT(ST_SHADE);
-                    px_shade(p, a, f, L);
+                    px_shade<!(NT == 1024 && HAS_MESH)>(p, a, f, L);
                 }
             }
         }
@@ -487,8 +487,9 @@ __global__ void rt_eval_kernel(int op, const uint32_t *in, uint32_t *out, int n)
         case 10: r = (float)rt_pow5((double)x); break;
         case 11: r = rt_rcp_in_range(x) ? rt_rcp_short(x) : 1.0f / x; break;       /* per lane what rt_rcp / rt_sqrt do per wave */
         case 12: r = rt_sqrt_in_range(x) ? rt_sqrt_short(x) : sqrtf(x); break;
-        case 13: r = rt_logf_0_1(rt_u01(u)); break;                                  /* the Box-Muller calls on a hash output */
+        case 13: r = rt_logf_0_1(rt_u01(u), 1); break;                               /* the Box-Muller calls on a hash output (13: the short divide, 15: the operator) */
         case 14: r = rt_cosf_0_2pi(rt_theta(u)); break;
+        case 15: r = rt_logf_0_1(rt_u01(u), 0); break;
         default: break;
     }
     out[i] = __float_as_uint(r);

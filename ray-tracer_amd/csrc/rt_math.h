@@ -166,7 +166,27 @@ RT_HD int rt__rem_pio2(float x, float *r_out)
  * rt_logf_0_1(rt_u01(r)) == rt_logf(rt_u01(r)) and rt_cosf_0_2pi(rt_theta(r)) == rt_cosf(rt_theta(r)) for every one of the 2^32
  * values of r.  (Below pi / 4 rt_cosf skips the reduction; here it runs and finds n = 0, r = x: x * (2 / pi) rounds to 0 and
  * fma(-0, P, x) is x.)  The oracle keeps calling rt_logf and rt_cosf. */
-RT_HD float rt_logf_0_1(float x)
+/* a / b for operands far from the ends of the binary32 range, from the correctly rounded reciprocal r = RN(1 / b): q0 = RN(a * r) is
+ * within an ulp of the quotient, its residual a - b * q0 is exact as an fma, and q0 + residual * r rounds to RN(a / b) (Markstein's
+ * theorem; it needs every intermediate to be a normal number, which the caller's operand ranges must guarantee).  On the device the
+ * reciprocal is v_rcp_f32 plus one correction step - equal to 1.0f / b for every b with 2^-126 <= |b| <= 2^126, checked for all
+ * 2^32 patterns (tests/test_gpu_math.py) - on the host the division operator.  Six instructions on the GPU where the compiler's IEEE
+ * expansion of a / b takes eleven (two v_div_scale, v_div_fmas and v_div_fixup deal with the operands this form excludes). */
+RT_HD float rt__div_benign(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y = __builtin_amdgcn_rcpf(b);
+    const float r = __builtin_fmaf(y, __builtin_fmaf(-b, y, 1.0f), y);
+#else
+    const float r = 1.0f / b;
+#endif
+    const float q0 = a * r;
+    return RT_FMAF(RT_FMAF(-b, q0, a), r, q0);
+}
+
+/* short_divide (a compile-time constant at every call): s = f / (2 + f) through rt__div_benign instead of the division operator - the
+ * same value; which one is faster depends on the kernel around it (profiles/r04/experiments/log_divide.txt) */
+RT_HD float rt_logf_0_1(float x, int short_divide)
 {
     const float LN2_HI = 0.693145751953125f;
     const float LN2_LO = 1.428606765330187e-06f;
@@ -178,7 +198,8 @@ RT_HD float rt_logf_0_1(float x)
     if (m >= 0x003504f4u) { mb = m | 0x3f000000u; k += 1; }
     else                  { mb = m | 0x3f800000u; }
     float f = rt_u2f(mb) - 1.0f;
-    float s = f / (2.0f + f);
+    /* f is 0 or 2^-24 <= |f| <= 0.415, 2 + f in [1.7, 2.42]: quotient, product and residual are all normal numbers (or exact zeros) */
+    float s = short_divide ? rt__div_benign(f, 2.0f + f) : f / (2.0f + f);
     float z = s * s;
     float R = z * RT_FMAF(z, RT_FMAF(z, RT_FMAF(z, 0.2222222222222222f, 0.2857142857142857f), 0.4f), 0.6666666666666666f);
     float hfsq = 0.5f * f * f;

@@ -28,6 +28,7 @@ void host_eval(int op, const uint32_t *in, uint32_t *out, int n)
             /* 13 / 14 on the device are rt_logf_0_1 / rt_cosf_0_2pi; the host answers with the GENERAL functions: the same values */
             case 13: r = rt_logf(rt_u01(u)); break;
             case 14: r = rt_cosf(rt_theta(u)); break;
+            case 15: r = rt_logf(rt_u01(u)); break;
         }
         memcpy(&out[i], &r, 4);
     }

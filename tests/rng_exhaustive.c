@@ -34,7 +34,8 @@ static void *work(void *arg)
         bj += fbits(rt_jitter(r)) != fbits(jit);
         bt += fbits(rt_theta(r)) != fbits(theta);
         /* the Box-Muller calls: log and cos restricted to the arguments a draw can produce against the general functions */
-        bl += fbits(rt_logf_0_1(rt_u01(r))) != fbits(rt_logf(rt_u01(r)));
+        bl += fbits(rt_logf_0_1(rt_u01(r), 0)) != fbits(rt_logf(rt_u01(r)));
+        bl += fbits(rt_logf_0_1(rt_u01(r), 1)) != fbits(rt_logf(rt_u01(r)));      /* ... with the division as reciprocal + residual step */
         bc += fbits(rt_cosf_0_2pi(rt_theta(r))) != fbits(rt_cosf(rt_theta(r)));
     }
     bad_u[id] = bu; bad_j[id] = bj; bad_t[id] = bt; bad_l[id] = bl; bad_c[id] = bc;
@@ -59,7 +60,8 @@ int main(int argc, char **argv)
         u += fbits(rt_u01(edge[i])) != fbits(uu);
         j += fbits(rt_jitter(edge[i])) != fbits((float)(((double)uu - 0.5) * 2 * (double)0.001f));
         t += fbits(rt_theta(edge[i])) != fbits((float)(2 * 3.14159 * (double)uu));
-        l += fbits(rt_logf_0_1(rt_u01(edge[i]))) != fbits(rt_logf(rt_u01(edge[i])));
+        l += fbits(rt_logf_0_1(rt_u01(edge[i]), 0)) != fbits(rt_logf(rt_u01(edge[i])));
+        l += fbits(rt_logf_0_1(rt_u01(edge[i]), 1)) != fbits(rt_logf(rt_u01(edge[i])));
         c += fbits(rt_cosf_0_2pi(rt_theta(edge[i]))) != fbits(rt_cosf(rt_theta(edge[i])));
     }
     printf("mismatches u01=%llu jitter=%llu theta=%llu log=%llu cos=%llu\n", (unsigned long long)u, (unsigned long long)j, (unsigned long long)t,

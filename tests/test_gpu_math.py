@@ -54,6 +54,8 @@ CASES = [
     # host the general rt_logf / rt_cosf on the same hash outputs (all 2^32 of them on the host alone: tests/test_rng_exhaustive.py)
     (13, "log of a draw", lambda r: np.concatenate([r.integers(0, 2**32, 4000000, dtype=np.uint64).astype(np.uint32), np.arange(0, 4096, dtype=np.uint32),
                                                     np.array([0x7fffffff, 0x80000000, 0xfffffffe, 0xffffffff], np.uint32)])),
+    (15, "log of a draw, division operator", lambda r: np.concatenate([r.integers(0, 2**32, 2000000, dtype=np.uint64).astype(np.uint32), np.arange(0, 4096, dtype=np.uint32),
+                                                                       np.array([0x7fffffff, 0x80000000, 0xfffffffe, 0xffffffff], np.uint32)])),
     (14, "cos of a draw", lambda r: np.concatenate([r.integers(0, 2**32, 4000000, dtype=np.uint64).astype(np.uint32), np.arange(0, 4096, dtype=np.uint32),
                                                     np.array([0x1fffffff, 0x20000000, 0x3fffffff, 0x40000000, 0x7fffffff, 0x80000000, 0xfffffffe, 0xffffffff], np.uint32)])),
 ]
