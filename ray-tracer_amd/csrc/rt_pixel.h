@@ -661,7 +661,17 @@ __device__ __forceinline__ void px_gen(Px &p, const rt_kernel_args &a, const Lds
                 float qc = dot(cq, cq) - ob.v[3] * ob.v[3];
                 float disc = qb * qb - 4.0f * qa * qc;
                 if (disc >= 0.0f) {
+#if defined(RT_SPHERE_IEEE_DIVIDE)
                     float dist = (-qb - rt_sqrt(disc)) / (2.0f * qa);
+#else
+                    /* The near root's division in its short form (rt_math.h rt__div_benign).  d is normalised or NaN, so the divisor is 2 to
+                     * within a few ulp (or NaN: NaN either way).  For a dividend that form's precondition excludes - below 2^-100 in magnitude,
+                     * or infinite - it may return another value than the operator, but never one that changes what follows: such a quotient is
+                     * below RT_EPS_F (rejected), or - an infinite dividend: inf from the operator, NaN from the short form - fails
+                     * `dist > RT_EPS_F` or `t <= best_t` (best_t <= 2^30) alike; every distance that IS accepted comes from a dividend between
+                     * 2e-6 and 2^31, where the two agree bit for bit. */
+                    float dist = rt__div_benign(-qb - rt_sqrt(disc), 2.0f * qa);
+#endif
                     if (dist > RT_EPS_F) { hit = true; t = dist; }
                 }
                 break;
