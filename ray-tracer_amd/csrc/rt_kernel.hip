@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : (HAS_MESH ? RT_SMALL_WG_WAVES 
                                         : (n_hit >= a.shade_batch || !others))) {
                 if (p.mode == M_SHADE) {
                     RT_STAT(ST_SHADE);
-                    px_shade<!(NT == 1024 && HAS_MESH)>(p, a, f, L);
+                    px_shade<!(NT == 1024 && HAS_MESH), MODE == RT_SCENE_HYBRID>(p, a, f, L);
                 }
             }
         }

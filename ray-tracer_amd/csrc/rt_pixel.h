@@ -95,7 +95,7 @@ __device__ __forceinline__ V3 neg(V3 a) { return v3(-a.x, -a.y, -a.z); }
 /* src/utils.cu:234-239 — Box-Muller cosine branch, theta drawn first.  rt_rng.h produces the
  * reference's (float)(r / 4294967295.0) and the binary64 products derived from it without the
  * binary64 divide, bit for bit (tests/test_rng_exhaustive.py covers all 2^32 inputs). */
-template <bool SHORT_DIVIDE>
+template <bool SHORT_DIVIDE, bool GENERAL_FUNCTIONS>
 __device__ __forceinline__ float normal_num(uint32_t &state)
 {
     float theta = rt_theta(rt_pcg_next(&state));
@@ -103,6 +103,10 @@ __device__ __forceinline__ float normal_num(uint32_t &state)
     float rho = rt_sqrt(-2.0f * rt_logf(rt_u01(rt_pcg_next(&state))));
     return rho * rt_cosf(theta);
 #else
+    if (GENERAL_FUNCTIONS) {         /* (the hybrid kernels: see px_shade) */
+        float rho_g = rt_sqrt(-2.0f * rt_logf(rt_u01(rt_pcg_next(&state))));
+        return rho_g * rt_cosf(theta);
+    }
     /* log on [0, 1] and cos on [0, 6.28318]: rt_logf / rt_cosf without the cases these arguments cannot be (rt_math.h) */
     float rho = rt_sqrt(-2.0f * rt_logf_0_1(rt_u01(rt_pcg_next(&state)), SHORT_DIVIDE ? 1 : 0));
     return rho * rt_cosf_0_2pi(theta);
@@ -403,7 +407,10 @@ __device__ __forceinline__ void px_shade_miss(Px &p, const rt_kernel_args &a, co
 /* ================= SHADE: the closest hit of this bounce is known (p.best_obj >= 0) ========= */
 /* SHORT_DIVIDE: the logarithm's division in its short form (rt_math.h rt__div_benign; the same values): faster in every kernel but the
  * 1024-thread mesh kernel (three-sphere -4.2 %, cube -1.4 %, monkey +0.4 %), which keeps the division operator */
-template <bool SHORT_DIVIDE>
+/* GENERAL_FUNCTIONS: Box-Muller through rt_logf / rt_cosf instead of their forms for a draw's arguments (again the same values): the hybrid
+ * kernels (nodes in LDS, triangles from L2) are 2.8 % FASTER that way on the 6,000-triangle scene and indifferent on the 50,880-triangle one
+ * (profiles/r04/experiments/box_muller_on_its_domain.txt) */
+template <bool SHORT_DIVIDE, bool GENERAL_FUNCTIONS>
 __device__ __forceinline__ void px_shade(Px &p, const rt_kernel_args &a, const Frame &f, const Lds &L)
 {
     V3 &o = p.o, &d = p.d;
@@ -476,9 +483,9 @@ __device__ __forceinline__ void px_shade(Px &p, const rt_kernel_args &a, const F
         if (do_reflect) {
             /* Ray::reflect src/ray.cu:67-75 with diffuse_reflect :157-170,
              * true_lambertian_reflect :172-178, perfect_reflect :180-186, lerp :32-34 */
-            float gx = normal_num<SHORT_DIVIDE>(p.rng);
-            float gy = normal_num<SHORT_DIVIDE>(p.rng);
-            float gz = normal_num<SHORT_DIVIDE>(p.rng);
+            float gx = normal_num<SHORT_DIVIDE, GENERAL_FUNCTIONS>(p.rng);
+            float gy = normal_num<SHORT_DIVIDE, GENERAL_FUNCTIONS>(p.rng);
+            float gz = normal_num<SHORT_DIVIDE, GENERAL_FUNCTIONS>(p.rng);
             V3 rv = v3(gx, gy, gz);
             if (dot(rv, N) < 0.0f) rv = neg(rv);
             rv = normalised(rv);
