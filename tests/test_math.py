@@ -89,3 +89,18 @@ def test_dense_accuracy_against_libm(tmp_path):
     assert v["log_ulp"] <= 1.0, out                    # measured 0.983 ulp
     assert v["sin_2m24"] <= 1.5 and v["cos_2m24"] <= 1.5 and v["bigarg_2m24"] <= 1.5, out     # measured 1.17 / 1.31 / 1.34 x 2^-24
     assert v["asin_abs"] < 1e-15 and v["acos_abs"] < 1e-15 and v["pow5_abs"] < 1e-15, out
+
+
+def test_short_division_equals_the_operator_where_its_call_sites_use_it(tmp_path):
+    """rt_math.h rt__div_benign (reciprocal + one residual step; Markstein) against `/` on 60 million random operand pairs per class:
+    a general benign class, the operands of Box-Muller's f / (2 + f), the sphere test's dividend / (2 |d|^2) from 2^-90 up.  (Below
+    ~2^-103 the residual underflows and quotients differ - the sphere test rejects such distances either way: rt_pixel.h.)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "divchk")
+    fma = ["-mfma"] if "fma" in open("/proc/cpuinfo").read().split() else []
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off"] + fma + [os.path.join(root, "tests", "div_benign_check.c"), "-o", exe, "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    assert "general 0, logarithm 0, sphere 0" in out.stdout
