@@ -671,8 +671,10 @@ __device__ __forceinline__ void px_gen(Px &p, const rt_kernel_args &a, const Lds
 #if defined(RT_SPHERE_IEEE_DIVIDE)
                     float dist = (-qb - rt_sqrt(disc)) / (2.0f * qa);
 #else
-                    /* The near root's division in its short form (rt_math.h rt__div_benign).  d is normalised or NaN, so the divisor is 2 to
-                     * within a few ulp (or NaN: NaN either way).  For a dividend that form's precondition excludes - below 2^-100 in magnitude,
+                    /* The near root's division in its short form (rt_math.h rt__div_benign).  d comes out of normalised(): a unit vector to a
+                     * few ulp, so the divisor is 2 to a few ulp - or d has a NaN (divisor NaN: the quotient is NaN either way), or it is the
+                     * zero vector (a vector whose squared length overflowed: then b and the dividend are zeros too and both forms give
+                     * 0 / 0 = NaN).  For a dividend that form's precondition excludes - below 2^-100 in magnitude,
                      * or infinite - it may return another value than the operator, but never one that changes what follows: such a quotient is
                      * below RT_EPS_F (rejected), or - an infinite dividend: inf from the operator, NaN from the short form - fails
                      * `dist > RT_EPS_F` or `t <= best_t` (best_t <= 2^30) alike; every distance that IS accepted comes from a dividend between
