@@ -474,6 +474,39 @@ def test_rays_with_a_zero_direction_component(rt, orc, ctx, models_dir, aa):
     assert eq(data.previous_render, want)
 
 
+@pytest.mark.parametrize("aa", [False, True])
+def test_extreme_operands_of_the_sphere_test(rt, orc, ctx, models_dir, aa):
+    """The device computes the sphere test's near root with a short division (rt_math.h rt__div_benign) whose precondition the code
+    argues from `d` being a unit vector (rt_pixel.h).  Here the operands the argument has to cover: cameras so far away that a ray's
+    squared length overflows (d = 0 or NaN), spheres at astronomic distances (infinite discriminants and dividends), a ray origin
+    exactly ON a sphere (dividends that cancel to ~0), radius 0 and a sphere around the camera, mixed with ordinary geometry so that
+    accepted hits exist next to the rejected ones.  The oracle divides with the operator: the frames must be the same bits."""
+    std = ("standard", (0.8, 0.7, 0.6), 0.3)
+    objs = [("sphere", (0.0, 0.0, -4.0), 1.0, std),
+            ("sphere", (0.0, -1001.0, -4.0), 1000.0, ("standard", (0.5, 0.5, 0.5), 0.0)),
+            ("sphere", (3.0e25, 1.0e25, -2.0e25), 1.0e24, ("emissive", (1.0, 1.0, 1.0), 3)),       # squared distances overflow
+            ("sphere", (-2.0, 0.5, -3.0), 0.0, std),                                               # radius 0
+            ("sphere", (0.0, 0.0, 0.0), 0.5, ("standard", (0.9, 0.2, 0.2), 0.8)),                   # the camera of the first view sits inside it
+            ("sphere", (1.5, 0.25, -3.5), 1.0e-20, std)]                                           # vanishing radius
+    W, H = 48, 32
+    sky = (0.5, 0.7, 1.0)
+    cams = [np.array([0, 0, 0, -1.5, 1.0, -2.0, 0.0625, 0, 0, 0, -0.0625, 0], np.float32),                      # ordinary (inside the red sphere)
+            np.array([1e20, 0, 0, -1.5, 1.0, -2.0, 0.0625, 0, 0, 0, -0.0625, 0], np.float32),                   # |direction|^2 overflows: d = 0
+            np.array([0, 0, 0, -3e38, 3e38, -3e38, 1e37, 0, 0, 0, -1e37, 0], np.float32),                       # infinite intermediate values
+            np.array([0, 0, -3.0, -1.5, 1.0, -5.0, 0.0625, 0, 0, 0, -0.0625, 0], np.float32),                   # origin exactly ON the unit sphere at (0, 0, -4)
+            np.array([0, 0, 0, -1.5e-30, 1.0e-30, -2.0e-30, 6.25e-32, 0, 0, 0, -6.25e-32, 0], np.float32)]      # a pixel grid 1e-30 wide
+    scene = ctx.commit(rt.SceneObjects(objs))
+    o = orc.Scene(objs, orc.MATH_DET, models_dir)
+    for i, cam in enumerate(cams):
+        data = rt.VariableRenderData(W, H)
+        rt.render(ctx, scene, rt.Camera(W, H, floats=cam), rt.RenderData(5, 6, aa, sky), data, 31 + i)
+        want = o.render(cam, W, H, 5, 6, sky, time_ms=31 + i, antialias=aa)
+        got = data.previous_render
+        nan_g, nan_w = np.isnan(got), np.isnan(want)
+        assert np.array_equal(nan_g, nan_w), i
+        assert eq(np.where(nan_g, 0, got), np.where(nan_w, 0, want)), i
+
+
 @pytest.mark.parametrize("name", ["monkey", "three_sphere"])
 def test_tiny_and_thin_images(rt, orc, ctx, models_dir, name):
     """images smaller than one tile, one pixel wide or high, one pixel in total"""
