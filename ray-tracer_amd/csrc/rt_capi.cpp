@@ -162,7 +162,7 @@ struct rt_ctx {
     int tile_scatter = 1;        /* RT_AMD_TILE_SCATTER=0: hand tiles out in raster order */
     int ready_break = RT_DEF_READY_BREAK;        /* lanes; RT_AMD_READY_BREAK; 65 = never */
     int hit_break = RT_DEF_HIT_BREAK;          /* lanes; RT_AMD_HIT_BREAK */
-    int hit_low = RT_DEF_HIT_LOW, mix_break = RT_DEF_MIX_BREAK;   /* RT_AMD_HIT_LOW, RT_AMD_MIX_BREAK (0 = that rule off) */
+    int hit_low = RT_DEF_HIT_LOW, mix_break = -1;                 /* RT_AMD_HIT_LOW, RT_AMD_MIX_BREAK (0 = that rule off; -1 = not set: the default of the scene's workgroup shape) */
     int shade_batch = RT_DEF_SHADE_BATCH;        /* lanes; RT_AMD_SHADE_BATCH (1..64) */
     Pipeline pipe;
     int pipe_share = 2;                          /* RT_AMD_PIPE_SHARE: pipelined frames run on 1 / depth of the CUs - 0 never, 1 always, 2 when a workgroup fills a CU */
@@ -796,8 +796,9 @@ static rt_status render_frames(rt_ctx *ctx, const rt_scene *scene, const rt_came
     a.work_threshold = ctx->work_threshold;
     a.ready_break = ctx->ready_break;
     a.hit_break = ctx->hit_break;
-    a.hit_low = ctx->hit_low > 0 && ctx->mix_break > 0 ? ctx->hit_low : ctx->hit_break;
-    a.mix_break = ctx->hit_low > 0 && ctx->mix_break > 0 ? ctx->mix_break : 1000;
+    const int mix_break = ctx->mix_break >= 0 ? ctx->mix_break : (scene->threads == 1024 ? RT_DEF_MIX_BREAK_1024 : RT_DEF_MIX_BREAK);
+    a.hit_low = ctx->hit_low > 0 && mix_break > 0 ? ctx->hit_low : ctx->hit_break;
+    a.mix_break = ctx->hit_low > 0 && mix_break > 0 ? mix_break : 1000;
     a.shade_batch = ctx->shade_batch;
     a.descend_keep = ctx->descend_keep;
     a.tri_uv = scene->d_tri_uv;
