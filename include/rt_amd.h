@@ -242,7 +242,7 @@ rt_status rt_render_device_batch(rt_ctx *ctx, const rt_scene *scene, const rt_ca
  * rt_render_device with the same seeds (tests/test_gpu_pipeline.py).  The loop becomes
  *     submit(t0); for (;;) { submit(now()); collect(n++, d_frame, s); draw(d_frame); }
  * i.e. the picture on screen lags the newest seed by the frames in flight.  Measured (monkey, 1920x1080x1024 spp, bench.py
- * "pipelined"): 8,950 Msamples/s with 4 frames in flight and 9,800 with 8, against 4,600 one launch at a time and 10,720 for
+ * "pipelined"): 8,950 Msamples/s with 4 frames in flight and 9,800 with 8, against 4,600 one launch at a time and 10,800 for
  * rt_render_device_batch.
  * A view's first frame or two (new scene / camera / size / tile spec) run alone: they measure the tiles and sort the schedule,
  * and the host waits for the frames in flight before it rewrites either.  rt_last_kernel_ms does not see pipelined frames;

@@ -47,13 +47,15 @@
  * profiles/r02/experiments/.  (Compiling them in as immediates instead of launch arguments was measured: no difference.) */
 #define RT_DEF_WORK_THRESHOLD 4      /* traversal steps run while at least this many lanes traverse (4 against 8, round 3: -0.6 % monkey, -0.9 % cube, +-0 reference scene 0, an eighth of the image -1 %) */
 #define RT_DEF_READY_BREAK 44        /* ... unless this many lanes have cheap work (generate / fetch / next mesh / a miss); 44 against 40 on round 4's final code: -0.3 % monkey, -0.6 % cube, +0.1 % reference scene 0 */
-#define RT_DEF_HIT_BREAK 24          /* ... or this many hold a hit to shade */
+#define RT_DEF_HIT_BREAK 32          /* ... or this many hold a hit to shade (24 until the end of round 4: on its final code, where a shade pass is ~15 % cheaper and the traversal
+                                         rounds between two of them count for more, 32 is -7.4 % on reference scene 0, -1.1 % cube, -0.3 % monkey: profiles/r04/experiments/knobs_final_build.txt) */
 #define RT_DEF_HIT_LOW 16            /* ... or at least this many hold a hit and, with the cheap-work lanes, they are */
 #define RT_DEF_MIX_BREAK 36          /*     this many together.  Re-swept on round 4's final code (the shade pass got cheaper, smaller batches pay sooner;
                                          profiles/r04/experiments/knobs_final_build.txt): 36 with ready_break 44 is +-0 on the cube's 256-thread workgroups ... */
 #define RT_DEF_MIX_BREAK_1024 32     /* ... and the 1024-thread kernels take 32: monkey -1.6 %, 50,880-triangle surface -1.7 %, 6,000-triangle soup -0.4 %, reference
                                          scenes 0 / 1 / 3 within 0.3 % (the cube would lose 0.5 % with it) */
-#define RT_DEF_DESCEND_KEEP 24       /* the descend loop ends once fewer than this many 64ths of its lanes remain */
+#define RT_DEF_DESCEND_KEEP 20       /* the descend loop ends once fewer than this many 64ths of its lanes remain (24 until the end of round 4; with hit_break 32: monkey -0.5 %, reference scene 0 -8.0 %,
+                                         50,880-triangle surface -1.3 %, cube -0.6 % against the defaults before) */
 #define RT_DEF_SHADE_BATCH 40        /* scenes without a mesh: hits are shaded once this many lanes hold one */
 /* What a pixel is charged for (the tile costs a view's first launch collects: longest-job-first schedule, cost-balanced
  * tile ownership over GPUs): per traversal macro step, per generated bounce ray, per shaded hit.  The ratios are what was
