@@ -49,3 +49,19 @@ def test_integration_md_c_snippets_compile(tmp_path):
 def test_header_mentions_no_removed_kernels():
     h = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
     assert "pooled kernel" not in h          # removed in round 3 (13d30ad)
+
+
+def test_documented_knob_defaults_are_the_headers():
+    """INTEGRATION.md §7 lists the scheduling knobs with their defaults; they must be the constants the library is built with"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "ray-tracer_amd", "csrc", "rt_device_scene.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    d = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define RT_DEF_([A-Z_0-9]+)\s+(\d+)", hdr)}
+    rows = {m.group(1): m.group(2).strip() for m in re.finditer(r"\| `(RT_AMD_[A-Z_]+)`(?:, `RT_AMD_[A-Z_]+`)? \| ([^|]+) \|", doc)}
+    assert rows["RT_AMD_WORK_THRESHOLD"] == str(d["WORK_THRESHOLD"])
+    assert rows["RT_AMD_READY_BREAK"] == str(d["READY_BREAK"])
+    assert rows["RT_AMD_HIT_BREAK"] == str(d["HIT_BREAK"])
+    assert rows["RT_AMD_DESCEND_KEEP"] == str(d["DESCEND_KEEP"])
+    assert rows["RT_AMD_SHADE_BATCH"] == str(d["SHADE_BATCH"])
+    assert rows["RT_AMD_HIT_LOW"].startswith("%d, %d (1024-thread workgroups) / %d" % (d["HIT_LOW"], d["MIX_BREAK_1024"], d["MIX_BREAK"]))
